@@ -1,0 +1,148 @@
+/*
+ * include/ndzip_hip.h -- C ABI of the MI355X (gfx950) back-end for ndzip's block encode/decode path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Every entry point names
+ * the reference interface it replaces (file:line relative to the celerity/ndzip tree).  The C++ adaptor
+ * classes with the reference's own virtual interfaces live in include/ndzip_hip.hh; the binding a
+ * maintainer would add to the reference is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - dtype: NDZIP_HIP_F32 (stream words are uint32_t) or NDZIP_HIP_F64 (stream words are uint64_t).
+ *   - dims in {1,2,3}; extent[d], d = 0 slowest (include/ndzip/ndzip.hh:172-180); all counts are uint32_t as
+ *     in the format (ndzip.hh:20).  Lengths are in stream words of the dtype.
+ *   - Every function returns NDZIP_HIP_OK (0) or a negative ndzip_hip_status; no exception crosses this ABI.
+ *     ndzip_hip_last_error() returns a thread-local description of the last failure.
+ *   - Handles are not thread-safe (same contract as the reference objects, which own mutable scratch:
+ *     src/ndzip/cuda_codec.inl:536-539); distinct handles are independent.
+ *   - Device-pointer entry points only enqueue work on the handle's hipStream_t; they never synchronise.
+ */
+#ifndef NDZIP_HIP_H
+#define NDZIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(NDZIP_HIP_BUILD)
+#define NDZIP_HIP_API __attribute__((visibility("default")))
+#else
+#define NDZIP_HIP_API
+#endif
+
+typedef enum ndzip_hip_dtype { NDZIP_HIP_F32 = 0, NDZIP_HIP_F64 = 1 } ndzip_hip_dtype;
+
+typedef enum ndzip_hip_status {
+    NDZIP_HIP_OK = 0,
+    NDZIP_HIP_ERR_INVALID_ARGUMENT = -1, /* bad dtype / dims / null pointer */
+    NDZIP_HIP_ERR_DIMS_MISMATCH = -2,    /* "data dimensionality does not match compressor dimensionality"
+                                            (std::runtime_error at src/ndzip/cuda_codec.inl:557-559, :631-633) */
+    NDZIP_HIP_ERR_CAPACITY = -3,         /* extent needs more hypercubes than the handle was created for */
+    NDZIP_HIP_ERR_RUNTIME = -4,          /* HIP runtime failure (cuda_check, src/ndzip/cuda_bits.cuh:165-169) */
+    NDZIP_HIP_ERR_NO_DEVICE = -5,        /* no gfx950 device visible: this back-end has NO CPU fallback */
+    NDZIP_HIP_ERR_DEVICE_FAULT = -6,     /* sticky device-side error word set (scan timeout / corrupt header) */
+    NDZIP_HIP_ERR_LIMIT = -7             /* element or word count does not fit the format's uint32_t */
+} ndzip_hip_status;
+
+typedef struct ndzip_hip_compressor ndzip_hip_compressor;
+typedef struct ndzip_hip_decompressor ndzip_hip_decompressor;
+
+/* Human-readable description of the last error on the calling thread ("" if none). */
+NDZIP_HIP_API const char *ndzip_hip_last_error(void);
+
+/* Library / device identification: writes the gfx arch name of the current device (e.g. "gfx950") and its CU
+ * count.  Fails with NDZIP_HIP_ERR_NO_DEVICE when no GPU is visible. */
+NDZIP_HIP_API int ndzip_hip_device_info(char *arch, size_t arch_capacity, int *num_compute_units);
+
+/* ---- sizing -------------------------------------------------------------------------------------------- */
+
+/* ndzip::compressed_length_bound<T>(extent)  (include/ndzip/ndzip.hh:224-225, src/ndzip/common.cc:31-55) */
+NDZIP_HIP_API int ndzip_hip_compressed_length_bound(int dtype, int dims, const uint32_t *extent, uint64_t *words);
+
+/* detail::num_hypercubes(extent)  (src/ndzip/common.hh:395-412); what compressor_requirements accumulates
+ * (include/ndzip/ndzip.hh:255-269, src/ndzip/common.cc:8-28). */
+NDZIP_HIP_API int ndzip_hip_num_hypercubes(int dims, const uint32_t *extent, uint32_t *num_hypercubes);
+
+/* Words of stream header for `num_hypercubes` (stream<Profile>::hypercube(0) - buffer, common.hh:350-358). */
+NDZIP_HIP_API int ndzip_hip_header_words(int dtype, uint32_t num_hypercubes, uint32_t *words);
+
+/* ---- device-pointer interface -------------------------------------------------------------------------- */
+
+/* make_cuda_compressor<T>(const compressor_requirements&, cudaStream_t)  (include/ndzip/cuda.hh:36-38,
+ * src/ndzip/cuda_factory.cu:4-9).  `max_num_hypercubes` is what compressor_requirements carries; scratch is
+ * allocated once here and reused by every compress call (cuda_codec.inl:543-552).  `hip_stream` is a
+ * hipStream_t (NULL = default stream). */
+NDZIP_HIP_API int ndzip_hip_compressor_create(
+        int dtype, int dims, uint32_t max_num_hypercubes, void *hip_stream, ndzip_hip_compressor **out);
+
+/* cuda_compressor<T>::compress(in_device_data, data_size, out_device_stream, out_device_stream_length)
+ * (include/ndzip/cuda.hh:10-23, src/ndzip/cuda_codec.inl:554-603).  Asynchronous on the handle's stream.
+ * `d_stream` must hold ndzip_hip_compressed_length_bound words; `d_stream_length_words` may be NULL. */
+NDZIP_HIP_API int ndzip_hip_compressor_compress(ndzip_hip_compressor *c, const void *d_in, int dims, const uint32_t *extent,
+        void *d_stream, uint32_t *d_stream_length_words);
+
+/* Same, with header and body written to separate device buffers and offsets local to this call: the
+ * building block of the multi-GPU path (no reference counterpart).  `d_header` receives
+ * num_hypercubes uint32 offset_after entries relative to `d_body`; `d_body_length_words` the body length
+ * (hypercube bodies followed by this extent's border). */
+NDZIP_HIP_API int ndzip_hip_compressor_compress_split(ndzip_hip_compressor *c, const void *d_in, int dims,
+        const uint32_t *extent, uint32_t *d_header, void *d_body, uint32_t *d_body_length_words);
+
+/* Adds `base` to `count` device-resident header entries (shard-local -> global offsets), asynchronously on
+ * the handle's stream. */
+NDZIP_HIP_API int ndzip_hip_compressor_offset_header(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, uint32_t base);
+
+/* Reads and clears the handle's sticky device error word; synchronises the handle's stream. */
+NDZIP_HIP_API int ndzip_hip_compressor_check(ndzip_hip_compressor *c);
+
+NDZIP_HIP_API int ndzip_hip_compressor_destroy(ndzip_hip_compressor *c);
+
+/* make_cuda_decompressor<T>(dims, cudaStream_t)  (include/ndzip/cuda.hh:40-41, src/ndzip/cuda_factory.cu:11-14) */
+NDZIP_HIP_API int ndzip_hip_decompressor_create(int dtype, int dims, void *hip_stream, ndzip_hip_decompressor **out);
+
+/* cuda_decompressor<T>::decompress(in_device_stream, out_device_data, data_size)
+ * (include/ndzip/cuda.hh:25-34, src/ndzip/cuda_codec.inl:628-652).  Asynchronous on the handle's stream. */
+NDZIP_HIP_API int ndzip_hip_decompressor_decompress(
+        ndzip_hip_decompressor *d, const void *d_stream, void *d_out, int dims, const uint32_t *extent);
+
+/* Split-buffer variant matching ndzip_hip_compressor_compress_split: `d_header` holds this extent's
+ * num_hypercubes offset_after entries minus `header_base` (the global offset of `d_body`'s first word). */
+NDZIP_HIP_API int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uint32_t *d_header,
+        uint32_t header_base, const void *d_body, void *d_out, int dims, const uint32_t *extent);
+
+NDZIP_HIP_API int ndzip_hip_decompressor_check(ndzip_hip_decompressor *d);
+NDZIP_HIP_API int ndzip_hip_decompressor_destroy(ndzip_hip_decompressor *d);
+
+/* ---- host-pointer interface ------------------------------------------------------------------------------ */
+
+/* offloader<T>::compress(data, data_size, stream, kernel_duration*)  (include/ndzip/offload.hh:16-19;
+ * behaviour of cuda_offloader::do_compress, src/ndzip/cuda_codec.inl:669-714): H2D copy, device pipeline timed
+ * with events (kernel_ns, may be NULL), D2H copy of length and stream.  `stream` must hold
+ * compressed_length_bound words; *stream_length_words receives the return value of the reference call. */
+NDZIP_HIP_API int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, const void *data, void *stream,
+        uint32_t *stream_length_words, uint64_t *kernel_ns);
+
+/* offloader<T>::decompress(stream, length, data, data_size, kernel_duration*)  (offload.hh:21-24;
+ * cuda_offloader::do_decompress, cuda_codec.inl:716-761).  *words_consumed receives the reference's return
+ * value (border offset + border words). */
+NDZIP_HIP_API int ndzip_hip_offload_decompress(int dtype, int dims, const uint32_t *extent, const void *stream,
+        uint32_t stream_length_words, void *data, uint32_t *words_consumed, uint64_t *kernel_ns);
+
+/* ---- stage entry points (parity tests; mirror the reference's stage-level tests
+ *      src/test/codec_profile_test.inl:514-549, :552-729, :735-801, :889-947) ----------------------------------- */
+
+/* stage: 0 forward transform of hypercube `hc` of the device array `d_in` -> 4096 residual words in `d_out`
+ *        1 encode 4096 residual words -> encoded run in `d_out` (4096 + 4096/B words capacity), *d_out_len words
+ *        2 decode an encoded run -> 4096 residual words
+ *        3 inverse transform of 4096 residual words -> hypercube `hc` of the device array `d_out`
+ *        4 / 5 32x32 bit transposes of `n` blocks of 32 uint32 (v_perm network / shift-mask network) */
+NDZIP_HIP_API int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in,
+        void *d_out, uint32_t *d_out_len, uint32_t n, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NDZIP_HIP_H */

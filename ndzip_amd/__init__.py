@@ -1,0 +1,23 @@
+"""ndzip_amd -- MI355X (gfx950) back-end for ndzip's block encode/decode path.
+
+Layout:
+  csrc/        hand-written HIP kernels + the C ABI (built in-tree into libndzip_hip.so by ndzip_amd.build)
+  hip.py       Python mirror of the reference's compressor / decompressor / offloader interfaces (ctypes)
+  sharded.py   multi-GPU hypercube-range sharding (one process per GPU, RCCL only for offsets + headers)
+  synth.py     deterministic integer-only synthetic grids
+"""
+from .hip import (  # noqa: F401
+    CompressorRequirements,
+    HipCompressor,
+    HipDecompressor,
+    HipOffloader,
+    NdzipHipError,
+    compressed_length_bound,
+    device_info,
+    header_words,
+    make_hip_compressor,
+    make_hip_decompressor,
+    make_hip_offloader,
+    num_hypercubes,
+    word_dtype,
+)

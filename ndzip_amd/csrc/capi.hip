@@ -1,0 +1,507 @@
+// ndzip_amd/csrc/capi.hip -- the C ABI declared in include/ndzip_hip.h, plus the border / bookkeeping kernels.
+//
+// Host logic mirrors the behaviour (not the code) of the reference drivers:
+//   cuda_compressor_impl::compress      src/ndzip/cuda_codec.inl:554-603
+//   cuda_decompressor_impl::decompress  src/ndzip/cuda_codec.inl:628-652
+//   cuda_offloader::do_compress / do_decompress  src/ndzip/cuda_codec.inl:669-761
+// There is NO CPU fallback: without a HIP device every compute entry point fails with NDZIP_HIP_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#define NDZIP_HIP_BUILD 1
+#include "../../include/ndzip_hip.h"
+#include "codec_common.hpp"
+#include "codec_launch.hpp"
+
+using namespace ndzip_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string &msg) {
+    g_last_error = msg;
+    return status;
+}
+
+int fail_hip(hipError_t e, const char *what) {
+    return fail(NDZIP_HIP_ERR_RUNTIME, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr);      \
+    } while (0)
+
+bool valid_dtype(int dtype) { return dtype == NDZIP_HIP_F32 || dtype == NDZIP_HIP_F64; }
+bool valid_dims(int dims) { return dims >= 1 && dims <= 3; }
+size_t word_bytes(int dtype) { return dtype == NDZIP_HIP_F32 ? 4 : 8; }
+uint32_t header_words_for(int dtype, uint32_t nhc) { return dtype == NDZIP_HIP_F32 ? nhc : (nhc + 1) / 2; }
+
+int ensure_device(int *num_cus) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void) hipGetLastError();
+        return fail(NDZIP_HIP_ERR_NO_DEVICE, "no HIP device visible: the ndzip HIP back-end has no CPU fallback");
+    }
+    if (num_cus) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    return NDZIP_HIP_OK;
+}
+
+// compressed_length_bound (common.cc:31-55), in 64 bits
+uint64_t length_bound(int dtype, const grid_geom &gg) {
+    const uint64_t B = dtype == NDZIP_HIP_F32 ? 32 : 64;
+    return header_words_for(dtype, gg.nhc) + static_cast<uint64_t>(gg.nhc) * (hc_size / B * (B + 1)) + border_count(gg);
+}
+
+// 16-byte vector path is legal when the base pointer and every hypercube-row start are 16-byte aligned
+bool is_aligned(int dtype, const grid_geom &gg, const void *data) {
+    const uint64_t ve = 16 / word_bytes(dtype);
+    if (reinterpret_cast<uintptr_t>(data) % 16 != 0) return false;
+    for (uint32_t d = 0; d + 1 < gg.dims; ++d) {
+        if (gg.stride[d] % ve != 0) return false;
+    }
+    return true;
+}
+
+int check_limits(int dtype, const grid_geom &gg) {
+    if (num_elements(gg) > 0xffffffffull) return fail(NDZIP_HIP_ERR_LIMIT, "extent has more than 2^32-1 elements (index_type is uint32_t)");
+    if (length_bound(dtype, gg) > 0xffffffffull) return fail(NDZIP_HIP_ERR_LIMIT, "compressed length bound exceeds 2^32-1 words");
+    return NDZIP_HIP_OK;
+}
+
+// ---- border gather/scatter (reference: compact_border / expand_border, cuda_codec.inl:463-474, :495-504) ------
+
+template<typename W, bool Pack>
+__global__ void border_kernel(W *data, W *body, const uint32_t *header, uint32_t nhc, uint32_t header_base, border_geom bg,
+        uint32_t *out_len, uint32_t len_extra) {
+    const uint64_t start = nhc ? header[nhc - 1] - header_base : 0u;  // stream<Profile>::border(), common.hh:365
+    W *border = body + start;
+    const uint64_t zpart = bg.cz * bg.per_z;
+    const uint64_t tails = bg.cy * bg.tail;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < bg.count;
+            i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        uint64_t src;
+        if (i >= zpart) {
+            src = bg.cz * bg.ny * bg.nx + (i - zpart);
+        } else {
+            const uint64_t z = i / bg.per_z, r = i % bg.per_z;
+            if (r < tails) {
+                src = (z * bg.ny + r / bg.tail) * bg.nx + bg.cx + r % bg.tail;
+            } else {
+                src = (z * bg.ny + bg.cy) * bg.nx + (r - tails);
+            }
+        }
+        if (Pack) {
+            border[i] = data[src];
+        } else {
+            data[src] = border[i];
+        }
+    }
+    // with zero hypercubes nobody else writes the stream length (store_stream_length, cuda_codec.inl:507-511)
+    if (Pack && out_len && nhc == 0 && blockIdx.x == 0 && threadIdx.x == 0) *out_len = len_extra;
+}
+
+__global__ void store_length_kernel(uint32_t *out_len, uint32_t value) { *out_len = value; }
+
+__global__ void offset_header_kernel(uint32_t *header, uint32_t count, uint32_t base) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += base;
+}
+
+template<bool Pack>
+hipError_t launch_border(int dtype, void *data, void *body, const uint32_t *header, uint32_t nhc, uint32_t header_base,
+        const border_geom &bg, uint32_t *out_len, uint32_t len_extra, hipStream_t stream) {
+    if (bg.count == 0) {
+        if (Pack && out_len && nhc == 0) hipLaunchKernelGGL(store_length_kernel, dim3(1), dim3(1), 0, stream, out_len, len_extra);
+        return hipGetLastError();
+    }
+    uint64_t blocks = (bg.count + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (dtype == NDZIP_HIP_F32) {
+        hipLaunchKernelGGL((border_kernel<uint32_t, Pack>), dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream,
+                static_cast<uint32_t *>(data), static_cast<uint32_t *>(body), header, nhc, header_base, bg, out_len, len_extra);
+    } else {
+        hipLaunchKernelGGL((border_kernel<uint64_t, Pack>), dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream,
+                static_cast<uint64_t *>(data), static_cast<uint64_t *>(body), header, nhc, header_base, bg, out_len, len_extra);
+    }
+    return hipGetLastError();
+}
+
+int check_error_word(uint32_t *d_err, hipStream_t stream) {
+    uint32_t host = 0;
+    HIP_TRY(hipMemcpyAsync(&host, d_err, sizeof host, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (host != 0) {
+        HIP_TRY(hipMemsetAsync(d_err, 0, sizeof host, stream));
+        char buf[160];
+        snprintf(buf, sizeof buf, "device error word 0x%x (%s%s)", host, (host & 1u) ? "scan look-back timeout " : "",
+                (host & 2u) ? "corrupt stream header" : "");
+        return fail(NDZIP_HIP_ERR_DEVICE_FAULT, buf);
+    }
+    return NDZIP_HIP_OK;
+}
+
+}  // namespace
+
+struct ndzip_hip_compressor {
+    int dtype;
+    int dims;
+    uint32_t max_nhc;
+    hipStream_t stream;
+    tile_desc *desc;
+    uint32_t *err;
+    int num_cus;
+};
+
+struct ndzip_hip_decompressor {
+    int dtype;
+    int dims;
+    hipStream_t stream;
+    uint32_t *err;
+};
+
+extern "C" {
+
+const char *ndzip_hip_last_error(void) { return g_last_error.c_str(); }
+
+int ndzip_hip_device_info(char *arch, size_t arch_capacity, int *num_compute_units) {
+    int cus = 0;
+    if (int s = ensure_device(&cus)) return s;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (arch && arch_capacity) {
+        std::string name = prop.gcnArchName;
+        const auto colon = name.find(':');
+        if (colon != std::string::npos) name.resize(colon);
+        snprintf(arch, arch_capacity, "%s", name.c_str());
+    }
+    if (num_compute_units) *num_compute_units = cus;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_compressed_length_bound(int dtype, int dims, const uint32_t *extent, uint64_t *words) {
+    if (!valid_dtype(dtype) || !valid_dims(dims) || !extent || !words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    *words = length_bound(dtype, make_geom(dims, extent));
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_num_hypercubes(int dims, const uint32_t *extent, uint32_t *num_hypercubes) {
+    if (!valid_dims(dims) || !extent || !num_hypercubes) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    *num_hypercubes = make_geom(dims, extent).nhc;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_header_words(int dtype, uint32_t num_hypercubes, uint32_t *words) {
+    if (!valid_dtype(dtype) || !words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    *words = header_words_for(dtype, num_hypercubes);
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_compressor_create(int dtype, int dims, uint32_t max_num_hypercubes, void *hip_stream, ndzip_hip_compressor **out) {
+    if (!out) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
+    *out = nullptr;
+    if (!valid_dtype(dtype)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid dtype");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");  // common.hh:642
+    int cus = 0;
+    if (int s = ensure_device(&cus)) return s;
+    auto *c = new ndzip_hip_compressor{dtype, dims, max_num_hypercubes, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, cus};
+    const uint32_t tiles = dtype == NDZIP_HIP_F32 ? compress_num_tiles<float>(dims, max_num_hypercubes)
+                                                  : compress_num_tiles<double>(dims, max_num_hypercubes);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->desc), (static_cast<size_t>(tiles) + 1) * sizeof(tile_desc));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->err), sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(c->err, 0, sizeof(uint32_t), c->stream);
+    if (e != hipSuccess) {
+        if (c->desc) (void) hipFree(c->desc);
+        if (c->err) (void) hipFree(c->err);
+        delete c;
+        return fail_hip(e, "allocating compressor scratch");
+    }
+    *out = c;
+    return NDZIP_HIP_OK;
+}
+
+static int compress_common(ndzip_hip_compressor *c, const void *d_in, int dims, const uint32_t *extent, uint32_t *d_header,
+        void *d_body, uint32_t *d_len, bool split) {
+    if (!c || !extent || !d_header || !d_body) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (dims != c->dims) return fail(NDZIP_HIP_ERR_DIMS_MISMATCH, "data dimensionality does not match compressor dimensionality");
+    const grid_geom gg = make_geom(dims, extent);
+    if (int s = check_limits(c->dtype, gg)) return s;
+    if (gg.nhc > c->max_nhc) return fail(NDZIP_HIP_ERR_CAPACITY, "extent has more hypercubes than the compressor was created for");
+    if (!d_in && num_elements(gg) > 0) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null input");
+    const border_geom bg = make_border_geom(gg);
+    const uint32_t hw = header_words_for(c->dtype, gg.nhc);
+    const uint32_t len_extra = (split ? 0u : hw) + static_cast<uint32_t>(bg.count);
+
+    compress_args a{};
+    a.in = d_in;
+    a.gg = gg;
+    a.header = d_header;
+    a.body = d_body;
+    a.desc = c->desc;
+    a.out_len = d_len;
+    a.len_extra = len_extra;
+    a.err = c->err;
+    a.stream = c->stream;
+    a.num_cus = c->num_cus;
+    a.aligned = is_aligned(c->dtype, gg, d_in);
+    if (gg.nhc > 0) {
+        HIP_TRY(c->dtype == NDZIP_HIP_F32 ? launch_compress<float>(dims, a) : launch_compress<double>(dims, a));
+    }
+    HIP_TRY(launch_border<true>(c->dtype, const_cast<void *>(d_in), d_body, d_header, gg.nhc, 0, bg, d_len, len_extra, c->stream));
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_compressor_compress(ndzip_hip_compressor *c, const void *d_in, int dims, const uint32_t *extent, void *d_stream,
+        uint32_t *d_stream_length_words) {
+    if (!c || !extent || !d_stream) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    const uint32_t nhc = make_geom(dims, extent).nhc;
+    const uint32_t hw = header_words_for(c->dtype, nhc);
+    void *body = static_cast<char *>(d_stream) + static_cast<size_t>(hw) * word_bytes(c->dtype);
+    return compress_common(c, d_in, dims, extent, static_cast<uint32_t *>(d_stream), body, d_stream_length_words, false);
+}
+
+int ndzip_hip_compressor_compress_split(ndzip_hip_compressor *c, const void *d_in, int dims, const uint32_t *extent,
+        uint32_t *d_header, void *d_body, uint32_t *d_body_length_words) {
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    return compress_common(c, d_in, dims, extent, d_header, d_body, d_body_length_words, true);
+}
+
+int ndzip_hip_compressor_offset_header(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, uint32_t base) {
+    if (!c || (!d_header && count)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (count == 0 || base == 0) return NDZIP_HIP_OK;
+    uint32_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(offset_header_kernel, dim3(blocks), dim3(256), 0, c->stream, d_header, count, base);
+    HIP_TRY(hipGetLastError());
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_compressor_check(ndzip_hip_compressor *c) {
+    if (!c) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle");
+    return check_error_word(c->err, c->stream);
+}
+
+int ndzip_hip_compressor_destroy(ndzip_hip_compressor *c) {
+    if (!c) return NDZIP_HIP_OK;
+    (void) hipStreamSynchronize(c->stream);
+    (void) hipFree(c->desc);
+    (void) hipFree(c->err);
+    delete c;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_decompressor_create(int dtype, int dims, void *hip_stream, ndzip_hip_decompressor **out) {
+    if (!out) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
+    *out = nullptr;
+    if (!valid_dtype(dtype)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid dtype");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    if (int s = ensure_device(nullptr)) return s;
+    auto *d = new ndzip_hip_decompressor{dtype, dims, static_cast<hipStream_t>(hip_stream), nullptr};
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d->err), sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d->err, 0, sizeof(uint32_t), d->stream);
+    if (e != hipSuccess) {
+        if (d->err) (void) hipFree(d->err);
+        delete d;
+        return fail_hip(e, "allocating decompressor scratch");
+    }
+    *out = d;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uint32_t *d_header, uint32_t header_base,
+        const void *d_body, void *d_out, int dims, const uint32_t *extent) {
+    if (!d || !extent || !d_body) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    if (dims != d->dims) return fail(NDZIP_HIP_ERR_DIMS_MISMATCH, "data dimensionality does not match decompressor dimensionality");
+    const grid_geom gg = make_geom(dims, extent);
+    if (int s = check_limits(d->dtype, gg)) return s;
+    if (!d_out && num_elements(gg) > 0) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null output");
+    if (!d_header && gg.nhc > 0) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null header");
+    decompress_args a{};
+    a.header = d_header;
+    a.header_base = header_base;
+    a.body = d_body;
+    a.out = d_out;
+    a.gg = gg;
+    a.err = d->err;
+    a.stream = d->stream;
+    a.aligned = is_aligned(d->dtype, gg, d_out);
+    if (gg.nhc > 0) {
+        HIP_TRY(d->dtype == NDZIP_HIP_F32 ? launch_decompress<float>(dims, a) : launch_decompress<double>(dims, a));
+    }
+    const border_geom bg = make_border_geom(gg);
+    HIP_TRY(launch_border<false>(d->dtype, d_out, const_cast<void *>(d_body), d_header, gg.nhc, header_base, bg, nullptr, 0, d->stream));
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_decompressor_decompress(ndzip_hip_decompressor *d, const void *d_stream, void *d_out, int dims, const uint32_t *extent) {
+    if (!d || !extent || !d_stream) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    const uint32_t nhc = make_geom(dims, extent).nhc;
+    const uint32_t hw = header_words_for(d->dtype, nhc);
+    const void *body = static_cast<const char *>(d_stream) + static_cast<size_t>(hw) * word_bytes(d->dtype);
+    return ndzip_hip_decompressor_decompress_split(d, static_cast<const uint32_t *>(d_stream), 0, body, d_out, dims, extent);
+}
+
+int ndzip_hip_decompressor_check(ndzip_hip_decompressor *d) {
+    if (!d) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle");
+    return check_error_word(d->err, d->stream);
+}
+
+int ndzip_hip_decompressor_destroy(ndzip_hip_decompressor *d) {
+    if (!d) return NDZIP_HIP_OK;
+    (void) hipStreamSynchronize(d->stream);
+    (void) hipFree(d->err);
+    delete d;
+    return NDZIP_HIP_OK;
+}
+
+// ---- host-pointer interface (cuda_offloader, cuda_codec.inl:654-761) ---------------------------------------------
+
+namespace {
+struct device_buffer {
+    void *p = nullptr;
+    ~device_buffer() {
+        if (p) (void) hipFree(p);
+    }
+    hipError_t allocate(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+struct event_pair {
+    hipEvent_t start = nullptr, stop = nullptr;
+    ~event_pair() {
+        if (start) (void) hipEventDestroy(start);
+        if (stop) (void) hipEventDestroy(stop);
+    }
+};
+}  // namespace
+
+int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, const void *data, void *stream,
+        uint32_t *stream_length_words, uint64_t *kernel_ns) {
+    if (!valid_dtype(dtype) || !extent || !stream || !stream_length_words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    if (int s = ensure_device(nullptr)) return s;
+    const grid_geom gg = make_geom(dims, extent);
+    if (int s = check_limits(dtype, gg)) return s;
+    const size_t wb = word_bytes(dtype);
+    const size_t in_bytes = num_elements(gg) * wb;
+    const size_t bound_bytes = length_bound(dtype, gg) * wb;
+    device_buffer d_in, d_stream, d_len;
+    HIP_TRY(d_in.allocate(in_bytes));
+    HIP_TRY(d_stream.allocate(bound_bytes));
+    HIP_TRY(d_len.allocate(sizeof(uint32_t)));
+    if (in_bytes) HIP_TRY(hipMemcpy(d_in.p, data, in_bytes, hipMemcpyHostToDevice));
+    ndzip_hip_compressor *c = nullptr;
+    if (int s = ndzip_hip_compressor_create(dtype, dims, gg.nhc, nullptr, &c)) return s;
+    event_pair ev;
+    int status = NDZIP_HIP_OK;
+    do {
+        if (kernel_ns) {
+            if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
+                status = fail(NDZIP_HIP_ERR_RUNTIME, "hipEventCreate failed");
+                break;
+            }
+            (void) hipEventRecord(ev.start, nullptr);
+        }
+        status = ndzip_hip_compressor_compress(c, d_in.p, dims, extent, d_stream.p, static_cast<uint32_t *>(d_len.p));
+        if (status) break;
+        if (kernel_ns) {
+            (void) hipEventRecord(ev.stop, nullptr);
+            (void) hipEventSynchronize(ev.stop);
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, ev.start, ev.stop);
+            *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+        }
+        status = ndzip_hip_compressor_check(c);
+    } while (false);
+    ndzip_hip_compressor_destroy(c);
+    if (status) return status;
+    uint32_t len = 0;
+    HIP_TRY(hipMemcpy(&len, d_len.p, sizeof len, hipMemcpyDeviceToHost));
+    if (static_cast<size_t>(len) * wb > bound_bytes) return fail(NDZIP_HIP_ERR_DEVICE_FAULT, "stream length exceeds bound");
+    if (len) HIP_TRY(hipMemcpy(stream, d_stream.p, static_cast<size_t>(len) * wb, hipMemcpyDeviceToHost));
+    *stream_length_words = len;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_offload_decompress(int dtype, int dims, const uint32_t *extent, const void *stream, uint32_t stream_length_words,
+        void *data, uint32_t *words_consumed, uint64_t *kernel_ns) {
+    if (!valid_dtype(dtype) || !extent || !stream) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    if (int s = ensure_device(nullptr)) return s;
+    const grid_geom gg = make_geom(dims, extent);
+    if (int s = check_limits(dtype, gg)) return s;
+    const size_t wb = word_bytes(dtype);
+    const size_t out_bytes = num_elements(gg) * wb;
+    // the stream must at least hold its header and the border (reference trusts `length`, cuda_codec.inl:726-730)
+    const uint64_t min_words = header_words_for(dtype, gg.nhc) + static_cast<uint64_t>(gg.nhc) * (hc_size / (wb * 8)) + border_count(gg);
+    if (stream_length_words < min_words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "stream shorter than its header and border");
+    device_buffer d_stream, d_out;
+    HIP_TRY(d_stream.allocate(static_cast<size_t>(stream_length_words) * wb));
+    HIP_TRY(d_out.allocate(out_bytes));
+    if (stream_length_words) HIP_TRY(hipMemcpy(d_stream.p, stream, static_cast<size_t>(stream_length_words) * wb, hipMemcpyHostToDevice));
+    ndzip_hip_decompressor *d = nullptr;
+    if (int s = ndzip_hip_decompressor_create(dtype, dims, nullptr, &d)) return s;
+    event_pair ev;
+    int status = NDZIP_HIP_OK;
+    do {
+        if (kernel_ns) {
+            if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
+                status = fail(NDZIP_HIP_ERR_RUNTIME, "hipEventCreate failed");
+                break;
+            }
+            (void) hipEventRecord(ev.start, nullptr);
+        }
+        status = ndzip_hip_decompressor_decompress(d, d_stream.p, d_out.p, dims, extent);
+        if (status) break;
+        if (kernel_ns) {
+            (void) hipEventRecord(ev.stop, nullptr);
+            (void) hipEventSynchronize(ev.stop);
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, ev.start, ev.stop);
+            *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+        }
+        status = ndzip_hip_decompressor_check(d);
+    } while (false);
+    ndzip_hip_decompressor_destroy(d);
+    if (status) return status;
+    if (out_bytes) HIP_TRY(hipMemcpy(data, d_out.p, out_bytes, hipMemcpyDeviceToHost));
+    if (words_consumed) {
+        // border offset + border words, recomputed from the header on the host (cuda_codec.inl:740-745)
+        uint32_t last = 0;
+        if (gg.nhc) last = static_cast<const uint32_t *>(stream)[gg.nhc - 1];
+        *words_consumed = header_words_for(dtype, gg.nhc) + last + static_cast<uint32_t>(border_count(gg));
+    }
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in, void *d_out,
+        uint32_t *d_out_len, uint32_t n, void *hip_stream) {
+    if (!valid_dtype(dtype) || !valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    if (int s = ensure_device(nullptr)) return s;
+    uint32_t one[3] = {side_for_dims(dims), side_for_dims(dims), side_for_dims(dims)};
+    const grid_geom gg = make_geom(dims, extent ? extent : one);
+    const void *array = stage == debug_forward_transform ? d_in : stage == debug_inverse_transform ? d_out : nullptr;
+    const bool aligned = array ? is_aligned(dtype, gg, array) : true;
+    if ((stage == debug_forward_transform || stage == debug_inverse_transform) && hc >= gg.nhc) {
+        return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "hypercube index out of range");
+    }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(dtype == NDZIP_HIP_F32 ? launch_debug_stage<float>(stage, dims, gg, hc, d_in, d_out, d_out_len, n, aligned, s)
+                                   : launch_debug_stage<double>(stage, dims, gg, hc, d_in, d_out, d_out_len, n, aligned, s));
+    return NDZIP_HIP_OK;
+}
+
+}  // extern "C"

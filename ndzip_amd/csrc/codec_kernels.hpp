@@ -1,0 +1,653 @@
+// ndzip_amd/csrc/codec_kernels.hpp -- gfx950 device code for the ndzip block encode/decode hot path.
+//
+// What is computed (bit-exact with the reference):
+//   encode: rotl1 -> integer Lorenzo differences along every axis -> complement_negative -> per chunk of B
+//           values: head = OR, BxB bit-plane transpose, non-zero planes appended      (reference CPU:
+//           src/ndzip/cpu_codec.inl:74-85,325-332,541-559; reference CUDA: src/ndzip/cuda_codec.inl:30-126,185-275)
+//   decode: the inverse (cpu_codec.inl:561-578,335-341,87-98; cuda_codec.inl:278-365,129-183,58-65)
+//
+// How it is mapped on CDNA4 (none of this mirrors the reference's warp-32 kernels):
+//   * 128 work-items (2 wavefronts) own one hypercube; work-item t owns the 32 consecutive cube-local values
+//     [32t, 32t+32).  For f32 that is exactly one chunk, for f64 half a chunk (lanes 2m, 2m+1 pair up).
+//   * The cube is staged once in LDS with a 16-byte pad after every 32 values, which makes every
+//     "work-item reads/writes its own 32 values with ds_*_b128" access bank-conflict free on the 64-bank LDS.
+//   * The forward Lorenzo transform is evaluated as one fused stencil straight out of that staging buffer
+//     (out-of-cube neighbours are read from a zero block), so there is a single barrier instead of one per axis.
+//   * The bit-plane transpose is a 5-stage in-register block-swap network per work-item (2x v_perm_b32 stages,
+//     3x shift+v_bfi stages): ~8 VALU ops per value instead of ~64 for a ballot per plane.
+//   * Chunk offsets inside a hypercube are a 128-wide scan done with wave shuffles; only ONE length per
+//     tile takes part in the device-wide scan, which is a decoupled look-back fused into the same kernel
+//     (traffic N + C instead of the reference's N + 3C).
+//   * The encoded hypercube is compacted in LDS and leaves as one contiguous, coalesced run.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "codec_common.hpp"
+
+namespace ndzip_hip {
+
+#define NDZIP_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------------------
+// small bit helpers (common.hh:436-449)
+// ---------------------------------------------------------------------------------------------------------
+
+NDZIP_DEV uint32_t rotl1(uint32_t v) { return __builtin_amdgcn_alignbit(v, v, 31); }
+NDZIP_DEV uint32_t rotr1(uint32_t v) { return __builtin_amdgcn_alignbit(v, v, 1); }
+NDZIP_DEV uint64_t rotl1(uint64_t v) { return (v << 1) | (v >> 63); }
+NDZIP_DEV uint64_t rotr1(uint64_t v) { return (v >> 1) | (v << 63); }
+
+// v >> (B-1) ? v ^ (~0 >> 1) : v   ==   v ^ (uint(sint(v) >> (B-1)) >> 1)
+NDZIP_DEV uint32_t complement_negative(uint32_t v) {
+    return v ^ (static_cast<uint32_t>(static_cast<int32_t>(v) >> 31) >> 1);
+}
+NDZIP_DEV uint64_t complement_negative(uint64_t v) {
+    return v ^ (static_cast<uint64_t>(static_cast<int64_t>(v) >> 63) >> 1);
+}
+
+NDZIP_DEV int popcount_w(uint32_t v) { return __builtin_popcount(v); }
+NDZIP_DEV int popcount_w(uint64_t v) { return __builtin_popcountll(v); }
+
+// ---------------------------------------------------------------------------------------------------------
+// 32x32 bit transpose, "mirrored" indexing of the format: out[i] bit (31-j) = in[j] bit (31-i)
+// (cpu_codec.inl:355-363).  Viewing word r as matrix row r with the MSB as column 0 this is the plain
+// matrix transpose; stage s swaps the off-diagonal s x s blocks.  The 64x64 transpose of f64 chunks is
+// four of these (see encode/decode below).
+// ---------------------------------------------------------------------------------------------------------
+
+template<int S, uint32_t M>
+NDZIP_DEV void swap_stage(uint32_t (&x)[32]) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        if ((r & S) == 0) {
+            const uint32_t a = x[r], b = x[r + S];
+            x[r] = (a & ~M) | ((b >> S) & M);      // v_lshrrev + v_bfi
+            x[r + S] = ((a << S) & ~M) | (b & M);  // v_lshlrev + v_bfi
+        }
+    }
+}
+
+NDZIP_DEV void transpose32(uint32_t (&x)[32]) {
+    // stages 16 and 8 move whole bytes: one v_perm_b32 per output word.
+    // __builtin_amdgcn_perm(hi, lo, sel): selector byte 0-3 picks lo.byte[0-3], 4-7 picks hi.byte[0-3].
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t a = x[r], b = x[r + 16];
+        x[r] = __builtin_amdgcn_perm(a, b, 0x07060302u);       // (a & 0xffff0000) | (b >> 16)
+        x[r + 16] = __builtin_amdgcn_perm(a, b, 0x05040100u);  // (a << 16) | (b & 0x0000ffff)
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        if ((r & 8) == 0) {
+            const uint32_t a = x[r], b = x[r + 8];
+            x[r] = __builtin_amdgcn_perm(a, b, 0x07030501u);      // (a & 0xff00ff00) | ((b >> 8) & 0x00ff00ff)
+            x[r + 8] = __builtin_amdgcn_perm(a, b, 0x06020400u);  // ((a << 8) & 0xff00ff00) | (b & 0x00ff00ff)
+        }
+    }
+    swap_stage<4, 0x0f0f0f0fu>(x);
+    swap_stage<2, 0x33333333u>(x);
+    swap_stage<1, 0x55555555u>(x);
+}
+
+// Portable shift/mask form of the same network; the unit test checks both against the oracle.
+NDZIP_DEV void transpose32_generic(uint32_t (&x)[32]) {
+    swap_stage<16, 0x0000ffffu>(x);
+    swap_stage<8, 0x00ff00ffu>(x);
+    swap_stage<4, 0x0f0f0f0fu>(x);
+    swap_stage<2, 0x33333333u>(x);
+    swap_stage<1, 0x55555555u>(x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS staging layout: value k lives at byte k*sizeof(W) + (k/32)*16.
+// ---------------------------------------------------------------------------------------------------------
+
+template<typename W>
+struct lds_layout {
+    static constexpr uint32_t chunk_bytes = 32 * sizeof(W) + 16;
+    static constexpr uint32_t cube_bytes = threads_per_hc * chunk_bytes;  // 18432 (f32) / 34816 (f64)
+    static constexpr uint32_t zero_bytes = 32 * sizeof(W);                // zero block for out-of-cube neighbours
+    NDZIP_DEV static uint32_t off(uint32_t k) { return k * static_cast<uint32_t>(sizeof(W)) + (k >> 5) * 16u; }
+};
+
+struct alignas(16) vec16 {
+    uint32_t w[4];
+};
+
+NDZIP_DEV vec16 lds_read16(const char *p) { return *reinterpret_cast<const vec16 *>(p); }
+NDZIP_DEV void lds_write16(char *p, vec16 v) { *reinterpret_cast<vec16 *>(p) = v; }
+
+template<typename W>
+NDZIP_DEV W lds_read(const char *base, uint32_t byte_off) {
+    return *reinterpret_cast<const W *>(base + byte_off);
+}
+
+// 16 consecutive values starting at value index k (k % 16 == 0, so the run never crosses a pad)
+template<typename W>
+NDZIP_DEV void read_run16(const char *p, W (&dst)[16]) {
+    constexpr int per = 16 / sizeof(W);  // values per 16-byte read
+#pragma unroll
+    for (int i = 0; i < 16 / per; ++i) {
+        const vec16 v = lds_read16(p + 16 * i);
+        if constexpr (sizeof(W) == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[4 * i + j] = v.w[j];
+        } else {
+            dst[2 * i] = static_cast<uint64_t>(v.w[0]) | (static_cast<uint64_t>(v.w[1]) << 32);
+            dst[2 * i + 1] = static_cast<uint64_t>(v.w[2]) | (static_cast<uint64_t>(v.w[3]) << 32);
+        }
+    }
+}
+
+template<typename W>
+NDZIP_DEV void write_run16(char *p, const W (&src)[16]) {
+    constexpr int per = 16 / sizeof(W);
+#pragma unroll
+    for (int i = 0; i < 16 / per; ++i) {
+        vec16 v;
+        if constexpr (sizeof(W) == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v.w[j] = src[4 * i + j];
+        } else {
+            v.w[0] = static_cast<uint32_t>(src[2 * i]);
+            v.w[1] = static_cast<uint32_t>(src[2 * i] >> 32);
+            v.w[2] = static_cast<uint32_t>(src[2 * i + 1]);
+            v.w[3] = static_cast<uint32_t>(src[2 * i + 1] >> 32);
+        }
+        lds_write16(p + 16 * i, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// hypercube <-> global addressing (common.hh:538-579)
+// ---------------------------------------------------------------------------------------------------------
+
+template<int Dims>
+NDZIP_DEV uint64_t hc_origin(const grid_geom &gg, uint32_t hc) {
+    constexpr uint32_t side = side_of<Dims>::value;
+    uint64_t off = 0;
+#pragma unroll
+    for (int nd = 0; nd < Dims; ++nd) {
+        const int d = Dims - 1 - nd;
+        const uint32_t c = hc % gg.g[d];
+        hc /= gg.g[d];
+        off += static_cast<uint64_t>(c) * side * gg.stride[d];
+    }
+    return off;
+}
+
+// element offset of cube-local index k relative to the hypercube origin
+template<int Dims>
+NDZIP_DEV uint64_t local_offset(const grid_geom &gg, uint32_t k) {
+    if constexpr (Dims == 1) {
+        return k;
+    } else if constexpr (Dims == 2) {
+        return static_cast<uint64_t>(k >> 6) * gg.stride[0] + (k & 63u);
+    } else {
+        return static_cast<uint64_t>(k >> 8) * gg.stride[0] + static_cast<uint64_t>((k >> 4) & 15u) * gg.stride[1]
+                + (k & 15u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// wave / group scans
+// ---------------------------------------------------------------------------------------------------------
+
+NDZIP_DEV uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+template<typename W>
+NDZIP_DEV W wave_inclusive_scan_w(W v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const W o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ENCODE one hypercube with 128 work-items.
+//   in        global array (as words)            origin   element offset of the hypercube
+//   cube      this hypercube's LDS staging region (lds_layout<W>::cube_bytes), reused for the encoded run
+//   zero      LDS zero block (lds_layout<W>::zero_bytes, 16-byte aligned)
+//   xchg      2 x uint32 LDS scratch for this hypercube
+// Returns the encoded length in words (uniform across the 128 work-items); the words sit at cube[0 .. L).
+// Contains __syncthreads(): every work-item of the workgroup must call it (`active` = false for padding
+// groups, which still take part in the barriers).
+// ---------------------------------------------------------------------------------------------------------
+
+template<typename T, int Dims, bool Aligned>
+NDZIP_DEV void forward_transform_hypercube(const typename profile<T, Dims>::word *__restrict__ in, const grid_geom &gg,
+        uint64_t origin, bool active, char *cube, const char *zero, int t,
+        typename profile<T, Dims>::word (&r)[vals_per_thread]) {
+    using P = profile<T, Dims>;
+    using W = typename P::word;
+    using L = lds_layout<W>;
+    constexpr int VE = 16 / sizeof(W);  // values per 16-byte vector
+
+    // ---- phase 0: coalesced global -> (rotl1) -> LDS -------------------------------------------------
+    if (active) {
+        if constexpr (Aligned) {
+            constexpr int NV = hc_size / VE / threads_per_hc;  // 8 (f32) / 16 (f64) vectors per work-item
+            vec16 v[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * VE;
+                v[i] = *reinterpret_cast<const vec16 *>(in + origin + local_offset<Dims>(gg, k));
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * VE;
+                vec16 r;
+                if constexpr (sizeof(W) == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r.w[j] = rotl1(v[i].w[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint64_t x = rotl1(static_cast<uint64_t>(v[i].w[2 * j])
+                                | (static_cast<uint64_t>(v[i].w[2 * j + 1]) << 32));
+                        r.w[2 * j] = static_cast<uint32_t>(x);
+                        r.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
+                    }
+                }
+                lds_write16(cube + L::off(k), r);
+            }
+        } else {
+            W v[vals_per_thread];
+#pragma unroll
+            for (int i = 0; i < vals_per_thread; ++i) {
+                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
+                v[i] = in[origin + local_offset<Dims>(gg, k)];
+            }
+#pragma unroll
+            for (int i = 0; i < vals_per_thread; ++i) {
+                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
+                *reinterpret_cast<W *>(cube + L::off(k)) = rotl1(v[i]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: fused Lorenzo stencil out of LDS -> residuals r[32] in registers ----------------------
+    const uint32_t k0 = static_cast<uint32_t>(t) * 32u;
+    const char *own = cube + L::off(k0);
+    if constexpr (Dims == 1) {
+        W o[32];
+        read_run16<W>(own, *reinterpret_cast<W(*)[16]>(&o[0]));
+        read_run16<W>(own + 16 * sizeof(W), *reinterpret_cast<W(*)[16]>(&o[16]));
+        // predecessor of the first value: last value of chunk t-1 (0 for the first value of the cube)
+        const W prev = lds_read<W>(t > 0 ? cube + L::off(k0 - 1) : zero, 0);
+#pragma unroll
+        for (int j = 31; j >= 1; --j) r[j] = o[j] - o[j - 1];
+        r[0] = o[0] - prev;
+    } else if constexpr (Dims == 2) {
+        // chunk = half a row: y = t / 2, h = t % 2
+        const int y = t >> 1, h = t & 1;
+        W o[32], u[32];
+        read_run16<W>(own, *reinterpret_cast<W(*)[16]>(&o[0]));
+        read_run16<W>(own + 16 * sizeof(W), *reinterpret_cast<W(*)[16]>(&o[16]));
+        const char *up = y > 0 ? cube + L::off(k0 - 64) : zero;
+        read_run16<W>(up, *reinterpret_cast<W(*)[16]>(&u[0]));
+        read_run16<W>(up + 16 * sizeof(W), *reinterpret_cast<W(*)[16]>(&u[16]));
+        const W ol = lds_read<W>(h ? cube + L::off(k0 - 1) : zero, 0);
+        const W ul = lds_read<W>((h && y > 0) ? cube + L::off(k0 - 65) : zero, 0);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) o[j] -= u[j];  // y difference
+        const W dl = ol - ul;
+#pragma unroll
+        for (int j = 31; j >= 1; --j) r[j] = o[j] - o[j - 1];  // x difference
+        r[0] = o[0] - dl;
+    } else {
+        // chunk = rows (z, y0) and (z, y0 + 1): z = t / 8, y0 = 2 * (t % 8)
+        const int z = t >> 3, yp = t & 7;
+        W a[16], b[16], p[16];
+        read_run16<W>(own, a);
+        read_run16<W>(own + 16 * sizeof(W), b);
+        read_run16<W>(yp > 0 ? cube + L::off(k0 - 16) : zero, p);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            b[j] -= a[j];  // row y0+1 minus row y0
+            a[j] -= p[j];  // row y0 minus row y0-1
+        }
+        {
+            W a1[16], b1[16], p1[16];
+            const char *below = z > 0 ? cube + L::off(k0 - 256) : zero;
+            read_run16<W>(below, a1);
+            read_run16<W>(z > 0 ? below + 16 * sizeof(W) : zero, b1);
+            read_run16<W>((z > 0 && yp > 0) ? cube + L::off(k0 - 256 - 16) : zero, p1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                b[j] -= b1[j] - a1[j];
+                a[j] -= a1[j] - p1[j];
+            }
+        }
+#pragma unroll
+        for (int j = 15; j >= 1; --j) {
+            r[j] = a[j] - a[j - 1];
+            r[16 + j] = b[j] - b[j - 1];
+        }
+        r[0] = a[0];
+        r[16] = b[0];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) r[j] = complement_negative(r[j]);
+
+    __syncthreads();  // all stencil reads done: `cube` may now be overwritten with the encoded run
+}
+
+// phase 2 of encode: residuals r[32] of work-item t -> encoded run at cube[0 .. L), returns L
+template<typename T, int Dims>
+NDZIP_DEV uint32_t encode_residuals(typename profile<T, Dims>::word (&r)[vals_per_thread], char *cube, uint32_t *xchg, int t) {
+    using P = profile<T, Dims>;
+    constexpr int B = P::B;
+    // ---- phase 2: head, in-register transpose, chunk-offset scan, compaction into LDS -------------------
+    const int lane = t & 63, wave = t >> 6;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(cube);
+    uint32_t total;
+    if constexpr (B == 32) {
+        uint32_t head = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) head |= r[j];
+        transpose32(r);
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(head));
+        const uint32_t incl = wave_inclusive_scan(cnt, lane);
+        if (lane == 63) xchg[wave] = incl;
+        __syncthreads();
+        const uint32_t wave_base = wave ? xchg[0] : 0u;
+        total = P::head_words + xchg[0] + xchg[1];
+        uint32_t pos = P::head_words + wave_base + incl - cnt;
+        out32[t] = head;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (r[i] != 0) out32[pos++] = r[i];
+        }
+    } else {
+        // f64: lanes (2m, 2m+1) share chunk m.  The even lane holds values 0..31 of the chunk (they land in
+        // bits 63..32 of every plane word), the odd lane values 32..63 (bits 31..0).  Plane i < 32 is built
+        // from the high halves of the values, plane i >= 32 from the low halves.
+        uint32_t hi[32], lo[32];
+        uint64_t own_or = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            own_or |= r[j];
+            hi[j] = static_cast<uint32_t>(r[j] >> 32);
+            lo[j] = static_cast<uint32_t>(r[j]);
+        }
+        const uint64_t head = own_or | __shfl_xor(own_or, 1, 64);
+        transpose32(hi);
+        transpose32(lo);
+        const bool upper = (t & 1) == 0;  // this lane supplies bits 63..32 (uint32 index 1 of the word)
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcountll(head));
+        const uint32_t incl = wave_inclusive_scan(upper ? cnt : 0u, lane);
+        if (lane == 63) xchg[wave] = incl;
+        __syncthreads();
+        const uint32_t wave_base = wave ? xchg[0] : 0u;
+        total = P::head_words + xchg[0] + xchg[1];
+        // exclusive offset of this chunk: inclusive value at the odd lane already contains the pair's count
+        uint32_t pos = P::head_words + wave_base + incl - cnt;
+        const uint32_t half = upper ? 1u : 0u;
+        out32[2 * (t >> 1) + half] = upper ? static_cast<uint32_t>(head >> 32) : static_cast<uint32_t>(head);
+        const uint32_t head_hi = static_cast<uint32_t>(head >> 32), head_lo = static_cast<uint32_t>(head);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if ((head_hi >> (31 - i)) & 1u) {
+                out32[2 * pos + half] = hi[i];
+                ++pos;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if ((head_lo >> (31 - i)) & 1u) {
+                out32[2 * pos + half] = lo[i];
+                ++pos;
+            }
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+template<typename T, int Dims, bool Aligned>
+NDZIP_DEV uint32_t encode_hypercube(const typename profile<T, Dims>::word *__restrict__ in, const grid_geom &gg,
+        uint64_t origin, bool active, char *cube, const char *zero, uint32_t *xchg, int t) {
+    typename profile<T, Dims>::word r[vals_per_thread];
+    forward_transform_hypercube<T, Dims, Aligned>(in, gg, origin, active, cube, zero, t, r);
+    return encode_residuals<T, Dims>(r, cube, xchg, t);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DECODE one hypercube with 128 work-items.
+//   stage   LDS region holding the encoded run, words [0, L) (same region as `cube`; it is consumed before
+//           the decoded values overwrite it)
+//   out     global array (as words), origin = element offset of the hypercube
+// ---------------------------------------------------------------------------------------------------------
+
+// phase 1 of decode: encoded run at cube[0 .. L) -> residuals r[32] of work-item t
+template<typename T, int Dims>
+NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typename profile<T, Dims>::word (&r)[vals_per_thread]) {
+    using P = profile<T, Dims>;
+    constexpr int B = P::B;
+    const int lane = t & 63, wave = t >> 6;
+    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(cube);
+
+    // ---- phase 1: heads -> chunk offsets -> gather planes -> inverse transpose -----------------------------
+    if constexpr (B == 32) {
+        const uint32_t head = in32[t];
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(head));
+        const uint32_t incl = wave_inclusive_scan(cnt, lane);
+        if (lane == 63) xchg[wave] = incl;
+        __syncthreads();
+        const uint32_t base = P::head_words + (wave ? xchg[0] : 0u) + incl - cnt;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            // planes above i that are present = set head bits among the top i bits
+            const uint32_t above = i == 0 ? 0u : (head & ~(0xffffffffu >> i));
+            const uint32_t w = in32[base + static_cast<uint32_t>(__builtin_popcount(above))];
+            r[i] = ((head >> (31 - i)) & 1u) ? w : 0u;
+        }
+        transpose32(r);
+    } else {
+        const bool upper = (t & 1) == 0;
+        const uint32_t half = upper ? 1u : 0u;
+        const uint32_t c = static_cast<uint32_t>(t >> 1);
+        const uint32_t head_lo = in32[2 * c], head_hi = in32[2 * c + 1];
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(head_lo) + __builtin_popcount(head_hi));
+        const uint32_t incl = wave_inclusive_scan(upper ? cnt : 0u, lane);
+        if (lane == 63) xchg[wave] = incl;
+        __syncthreads();
+        const uint32_t base = P::head_words + (wave ? xchg[0] : 0u) + incl - cnt;
+        const uint32_t n_hi = static_cast<uint32_t>(__builtin_popcount(head_hi));
+        uint32_t hi[32], lo[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t above = i == 0 ? 0u : (head_hi & ~(0xffffffffu >> i));
+            const uint32_t w = in32[2 * (base + static_cast<uint32_t>(__builtin_popcount(above))) + half];
+            hi[i] = ((head_hi >> (31 - i)) & 1u) ? w : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t above = i == 0 ? 0u : (head_lo & ~(0xffffffffu >> i));
+            const uint32_t w = in32[2 * (base + n_hi + static_cast<uint32_t>(__builtin_popcount(above))) + half];
+            lo[i] = ((head_lo >> (31 - i)) & 1u) ? w : 0u;
+        }
+        transpose32(hi);
+        transpose32(lo);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) r[j] = (static_cast<uint64_t>(hi[j]) << 32) | lo[j];
+    }
+}
+
+// phases 2+3 of decode: residuals -> complement_negative -> prefix sums along every axis -> rotr1 -> global
+template<typename T, int Dims, bool Aligned>
+NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[vals_per_thread],
+        typename profile<T, Dims>::word *__restrict__ out, const grid_geom &gg, uint64_t origin, bool active, char *cube,
+        uint32_t *xchg, int t) {
+    using P = profile<T, Dims>;
+    using W = typename P::word;
+    using L = lds_layout<W>;
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) r[j] = complement_negative(r[j]);
+
+    // ---- phase 2: prefix sums that stay inside the work-item / wavefront ----------------------------------
+    if constexpr (Dims == 1) {
+#pragma unroll
+        for (int j = 1; j < 32; ++j) r[j] += r[j - 1];
+        const W incl = wave_inclusive_scan_w<W>(r[31], lane);
+        W *xw = reinterpret_cast<W *>(xchg + 2);  // 2 words of W after the two uint32
+        __syncthreads();                           // xchg[0..1] reads above are complete
+        if (lane == 63) xw[wave] = incl;
+        __syncthreads();
+        const W carry = incl - r[31] + (wave ? xw[0] : W{0});
+#pragma unroll
+        for (int j = 0; j < 32; ++j) r[j] += carry;
+    } else if constexpr (Dims == 2) {
+#pragma unroll
+        for (int j = 1; j < 32; ++j) r[j] += r[j - 1];
+        const W left = __shfl_up(r[31], 1, 64);
+        if (t & 1) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) r[j] += left;
+        }
+    } else {
+        // x within each row, then y: second row += first row, scan of row pairs over the 8 lanes of a z-plane
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+            r[j] += r[j - 1];
+            r[16 + j] += r[16 + j - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r[16 + j] += r[j];
+        const int yp = t & 7;
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const W o = __shfl_up(r[16 + j], d, 8);
+                if (yp >= d) r[16 + j] += o;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const W o = __shfl_up(r[16 + j], 1, 8);
+            // rows of this lane: first row gets the inclusive total of the previous lane; the second row
+            // already holds the inclusive total of this lane
+            if (yp > 0) r[j] += o;
+        }
+    }
+
+    __syncthreads();  // every work-item has consumed the encoded run: overwrite `cube` with values
+    {
+        char *own = cube + L::off(static_cast<uint32_t>(t) * 32u);
+        write_run16<W>(own, *reinterpret_cast<W(*)[16]>(&r[0]));
+        write_run16<W>(own + 16 * sizeof(W), *reinterpret_cast<W(*)[16]>(&r[16]));
+    }
+    __syncthreads();
+
+    // ---- phase 3: remaining axis sums in the store layout, rotr1, coalesced global store ---------------------
+    if (!active) return;
+    if constexpr (Dims == 1) {
+        if constexpr (Aligned) {
+            constexpr int VE = 16 / sizeof(W);
+            constexpr int NV = hc_size / VE / threads_per_hc;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * VE;
+                vec16 v = lds_read16(cube + L::off(k));
+                if constexpr (sizeof(W) == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v.w[j] = rotr1(v.w[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint64_t x = rotr1(static_cast<uint64_t>(v.w[2 * j]) | (static_cast<uint64_t>(v.w[2 * j + 1]) << 32));
+                        v.w[2 * j] = static_cast<uint32_t>(x);
+                        v.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
+                    }
+                }
+                *reinterpret_cast<vec16 *>(out + origin + k) = v;
+            }
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < vals_per_thread; ++i) {
+                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
+                out[origin + k] = rotr1(lds_read<W>(cube, L::off(k)));
+            }
+        }
+    } else if constexpr (Dims == 2) {
+        // work-item = column x of one half of the rows; the second half first accumulates the first half
+        const uint32_t x = static_cast<uint32_t>(t) & 63u;
+        const int half = t >> 6;
+        W acc = 0;
+        if (half) {
+#pragma unroll 8
+            for (uint32_t y = 0; y < 32; ++y) acc += lds_read<W>(cube, L::off(y * 64 + x));
+        }
+        const uint32_t y0 = half ? 32u : 0u;
+#pragma unroll 8
+        for (uint32_t y = y0; y < y0 + 32; ++y) {
+            acc += lds_read<W>(cube, L::off(y * 64 + x));
+            out[origin + static_cast<uint64_t>(y) * gg.stride[0] + x] = rotr1(acc);
+        }
+    } else {
+        // work-item = (y, pair of x) for all 16 z
+        const uint32_t y = static_cast<uint32_t>(t) >> 3, xp = static_cast<uint32_t>(t) & 7u;
+        W acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (uint32_t z = 0; z < 16; ++z) {
+            const uint32_t k = z * 256 + y * 16 + 2 * xp;
+            const char *p = cube + L::off(k);
+            const uint64_t g = origin + static_cast<uint64_t>(z) * gg.stride[0] + static_cast<uint64_t>(y) * gg.stride[1] + 2 * xp;
+            if constexpr (sizeof(W) == 4) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(p);
+                acc0 += v.x;
+                acc1 += v.y;
+                if constexpr (Aligned) {
+                    *reinterpret_cast<uint2 *>(out + g) = make_uint2(rotr1(acc0), rotr1(acc1));
+                } else {
+                    out[g] = rotr1(acc0);
+                    out[g + 1] = rotr1(acc1);
+                }
+            } else {
+                const vec16 v = lds_read16(p);
+                acc0 += static_cast<uint64_t>(v.w[0]) | (static_cast<uint64_t>(v.w[1]) << 32);
+                acc1 += static_cast<uint64_t>(v.w[2]) | (static_cast<uint64_t>(v.w[3]) << 32);
+                const uint64_t o0 = rotr1(acc0), o1 = rotr1(acc1);
+                if constexpr (Aligned) {
+                    vec16 w;
+                    w.w[0] = static_cast<uint32_t>(o0);
+                    w.w[1] = static_cast<uint32_t>(o0 >> 32);
+                    w.w[2] = static_cast<uint32_t>(o1);
+                    w.w[3] = static_cast<uint32_t>(o1 >> 32);
+                    *reinterpret_cast<vec16 *>(out + g) = w;
+                } else {
+                    out[g] = o0;
+                    out[g + 1] = o1;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace ndzip_hip
+
+namespace ndzip_hip {
+
+template<typename T, int Dims, bool Aligned>
+NDZIP_DEV void decode_hypercube(typename profile<T, Dims>::word *__restrict__ out, const grid_geom &gg, uint64_t origin,
+        bool active, char *cube, uint32_t *xchg, int t) {
+    typename profile<T, Dims>::word r[vals_per_thread];
+    decode_residuals<T, Dims>(cube, xchg, t, r);
+    inverse_transform_hypercube<T, Dims, Aligned>(r, out, gg, origin, active, cube, xchg, t);
+}
+
+}  // namespace ndzip_hip

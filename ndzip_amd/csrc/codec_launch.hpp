@@ -1,0 +1,80 @@
+// ndzip_amd/csrc/codec_launch.hpp -- host-visible launch interface between the C ABI (capi.hip) and the
+// per-type kernel translation units (kernels_f32.hip / kernels_f64.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "codec_common.hpp"
+
+namespace ndzip_hip {
+
+// Tile descriptor of the fused decoupled look-back scan: (status << 32) | value, written with ONE relaxed
+// agent-scope 8-byte store, so the value is its own flag (no fences; MI355X guide section 6 G16 "R2").
+using tile_desc = unsigned long long;
+
+struct compress_args {
+    const void *in;        // device, value_type[num_elements]
+    grid_geom gg;
+    uint32_t *header;      // device, NHC uint32 entries (+1 pad entry for 64-bit streams with odd NHC)
+    void *body;            // device, first body word (= stream + header words for a contiguous stream)
+    tile_desc *desc;       // device scratch, >= num_tiles entries, zeroed by the launcher on `stream`
+    uint32_t *out_len;     // device scalar or nullptr
+    uint32_t len_extra;    // header words + border words, added to the body length for *out_len
+    uint32_t *err;         // device error word (sticky)
+    hipStream_t stream;
+    int num_cus;
+    bool aligned;          // 16-byte aligned base and row strides
+};
+
+struct decompress_args {
+    const uint32_t *header;   // NHC offset_after entries
+    uint32_t header_base;     // value the entries are relative to (0 for a whole stream; the global offset of
+                              // `body`'s first word for a shard)
+    const void *body;
+    void *out;
+    grid_geom gg;
+    uint32_t *err;
+    hipStream_t stream;
+    bool aligned;
+};
+
+// hypercubes per compress / decompress workgroup for (T, dims)
+template<typename T>
+int compress_hcs_per_group(int dims);
+
+template<typename T>
+uint32_t compress_num_tiles(int dims, uint32_t nhc);
+
+template<typename T>
+hipError_t launch_compress(int dims, const compress_args &a);
+
+template<typename T>
+hipError_t launch_decompress(int dims, const decompress_args &a);
+
+// ---- stage entry points used by the parity tests (one hypercube, 128 work-items) -------------------------
+enum debug_stage : int {
+    debug_forward_transform = 0,  // in: array + geometry, hc index   -> out: 4096 residual words
+    debug_encode_residuals = 1,   // in: 4096 residual words          -> out: encoded run, out_len = words
+    debug_decode_residuals = 2,   // in: encoded run                  -> out: 4096 residual words
+    debug_inverse_transform = 3,  // in: 4096 residual words          -> out: array (hypercube hc of geometry)
+    debug_transpose32 = 4,        // in: n*32 uint32                  -> out: n*32 uint32 (v_perm network)
+    debug_transpose32_generic = 5,
+};
+
+template<typename T>
+hipError_t launch_debug_stage(int stage, int dims, const grid_geom &gg, uint32_t hc, const void *in, void *out,
+        uint32_t *out_len, uint32_t n, bool aligned, hipStream_t stream);
+
+// explicit specialisations live in kernels_f32.hip / kernels_f64.hip
+#define NDZIP_DECLARE_LAUNCHERS(T)                                                                                     \
+    template<> int compress_hcs_per_group<T>(int);                                                                    \
+    template<> uint32_t compress_num_tiles<T>(int, uint32_t);                                                         \
+    template<> hipError_t launch_compress<T>(int, const compress_args &);                                            \
+    template<> hipError_t launch_decompress<T>(int, const decompress_args &);                                        \
+    template<> hipError_t launch_debug_stage<T>(int, int, const grid_geom &, uint32_t, const void *, void *, uint32_t *, \
+            uint32_t, bool, hipStream_t);
+NDZIP_DECLARE_LAUNCHERS(float)
+NDZIP_DECLARE_LAUNCHERS(double)
+#undef NDZIP_DECLARE_LAUNCHERS
+
+}  // namespace ndzip_hip

@@ -1,0 +1,165 @@
+"""End-to-end parity of the HIP path against the CPU oracle through the C ABI (bit-exact streams).
+
+Mirrors src/test/codec_profile_test.inl:
+  decode(encode(x)) == x for extent (4*side-1)^dims with the first chunk zeroed, all pairings   :37-96
+  headers identical + same length                                                              :100-140
+  single hypercube compresses identically / decompresses correctly                            :952-1043
+  extents 0 and 1 (zero hypercubes)                                                            :1045-1082
+plus the known answers recorded in SURVEY.md section 8a from the compiled reference, odd-NHC header padding
+for f64, unaligned extents (scalar load path) and the host-pointer offloader."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.util import (PROFILES, SIDE, device_compress, device_decompress, profile_id, random_bits, random_unit_floats,
+                        same_bits, word_dtype)
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_stream(data):
+    want = oracle.compress(data)
+    got = device_compress(data)
+    assert len(got) == len(want), (len(got), len(want))
+    nhc = oracle.num_hypercubes(data.shape)
+    hdr = np.frombuffer(got.tobytes(), dtype=np.uint32)[:nhc]
+    hdr_want = np.frombuffer(want.tobytes(), dtype=np.uint32)[:nhc]
+    assert np.array_equal(hdr, hdr_want), "header entries differ"
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, f"first differing words {bad[:8]}"
+    return got
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_roundtrip_all_pairings_with_border(hiplib, cuda_device, profile):
+    dtype, dims = profile
+    n = SIDE[dims] * 4 - 1
+    if dims == 1:
+        n = SIDE[dims] * 4 - 1
+    shape = (n,) * dims
+    data = random_unit_floats(shape, dtype, 21)
+    data.reshape(-1)[: np.dtype(dtype).itemsize * 8] = 0  # regression input of :49-50
+    stream = _check_stream(data)
+    # HIP compress => HIP decompress, HIP compress => oracle decompress, oracle compress => HIP decompress
+    assert same_bits(device_decompress(stream, dtype, shape), data)
+    back, consumed = oracle.decompress(stream, dtype, shape)
+    assert consumed == len(stream) and same_bits(back, data)
+    assert same_bits(device_decompress(oracle.compress(data), dtype, shape), data)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_single_hypercube(hiplib, cuda_device, profile):
+    dtype, dims = profile
+    shape = (SIDE[dims],) * dims
+    data = random_unit_floats(shape, dtype, 22)
+    stream = _check_stream(data)
+    assert same_bits(device_decompress(stream, dtype, shape), data)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+@pytest.mark.parametrize("n", [0, 1])
+def test_zero_hypercubes(hiplib, cuda_device, profile, n):
+    dtype, dims = profile
+    shape = (n,) * dims
+    data = np.full(shape, 42, dtype=dtype)
+    stream = _check_stream(data)
+    assert len(stream) == n
+    if n:
+        assert same_bits(device_decompress(stream, dtype, shape), data)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+@pytest.mark.parametrize("kind", ["bits", "unit", "synthetic"])
+def test_many_hypercubes_unaligned_and_aligned(hiplib, cuda_device, profile, kind):
+    from ndzip_amd.synth import synth_numpy
+
+    dtype, dims = profile
+    side = SIDE[dims]
+    shapes = {1: [(side * 37,), (side * 5 + 17,)], 2: [(side * 5, side * 6), (side * 3 + 1, side * 4 + 3)],
+              3: [(side * 3, side * 4, side * 6), (side * 2 + 5, side * 3 + 1, side * 3 + 2)]}[dims]
+    for i, shape in enumerate(shapes):
+        if kind == "bits":
+            data = random_bits(shape, dtype, 30 + i)
+        elif kind == "unit":
+            data = random_unit_floats(shape, dtype, 40 + i)
+        else:
+            data = synth_numpy(shape, dtype, seed=50 + i, noise_mask=0xFF)
+        stream = _check_stream(data)
+        assert same_bits(device_decompress(stream, dtype, shape), data)
+
+
+def test_f64_odd_hypercube_count_zeroes_header_pad(hiplib, cuda_device):
+    # 1D f64 3x4096 zeros -> len 194, header {0x40, 0x80, 0xc0, pad 0}
+    data = np.zeros(3 * 4096, dtype=np.float64)
+    stream = _check_stream(data)
+    assert len(stream) == 194
+    assert stream[0] == 0x0000008000000040 and stream[1] == 0x00000000000000C0
+    data2 = random_unit_floats((200, 70), np.float64, 7)  # NHC = 3
+    stream2 = _check_stream(data2)
+    assert np.frombuffer(stream2.tobytes(), dtype=np.uint32)[3] == 0
+
+
+def test_known_answers_from_reference(hiplib, cuda_device):
+    """Known answers captured from the compiled reference."""
+    s = device_compress(np.zeros(4096, np.float32))
+    assert len(s) == 129 and s[0] == 0x80 and not s[1:].any()
+    s = device_compress(np.ones(4096, np.float32))
+    assert len(s) == 136 and s[0] == 0x87 and s[1] == 0x7F000000 and not s[2:129].any() and (s[129:] == 0x80000000).all()
+    s = device_compress(np.ones((16, 16, 16), np.float32))
+    assert len(s) == 136 and s[0] == 0x87
+    s = device_compress(np.ones(4096, np.float64))
+    assert len(s) == 75 and s[0] == 0x4A and s[1] == 0x7FE0000000000000 and (s[65:] == 0x8000000000000000).all()
+    z = np.zeros(4096, np.float32)
+    z[0] = -0.0
+    s = device_compress(z)
+    assert len(s) == 131 and s[1] == 0x80000001 and s[129] == 0x40000000 and s[130] == 0x80000000
+    b = np.zeros(4099, np.float32)
+    b[4096:] = [1, 2, -1]
+    s = device_compress(b)
+    assert len(s) == 132 and list(s[-3:]) == [0x3F800000, 0x40000000, 0xBF800000]
+    s = device_compress(np.arange(5, dtype=np.float32))
+    assert len(s) == 5
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_host_pointer_offloader(hiplib, cuda_device, profile):
+    """offloader<T>::compress / decompress semantics (offload.hh:16-24): return values and kernel_duration."""
+    import ndzip_amd
+
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 3 + 9,), 2: (side * 2 + 5, side * 3), 3: (side * 2, side * 2 + 3, side * 2)}[dims]
+    data = random_unit_floats(shape, dtype, 60)
+    off = ndzip_amd.make_hip_offloader(dtype, dims)
+    stream = off.compress(data)
+    assert off.last_kernel_ns > 0
+    assert np.array_equal(stream, oracle.compress(data))
+    back, consumed = off.decompress(stream, shape)
+    assert consumed == len(stream)
+    assert same_bits(back, data)
+    with pytest.raises(ndzip_amd.NdzipHipError, match="dimensionality"):
+        ndzip_amd.make_hip_offloader(dtype, 3 if dims != 3 else 2).compress(data)
+
+
+def test_compressor_reuse_and_capacity(hiplib, cuda_device):
+    """One compressor object serves several extents up to its requirements (cuda_codec.inl:543-552)."""
+    import torch
+
+    import ndzip_amd
+
+    req = ndzip_amd.CompressorRequirements((64 * 3, 64 * 2), (64, 64 * 5))
+    assert req.max_num_hypercubes == 6
+    comp = ndzip_amd.make_hip_compressor(np.float32, req)
+    for shape in [(64 * 3, 64 * 2), (64, 64 * 5), (70, 130)]:
+        data = random_unit_floats(shape, np.float32, 70)
+        d_in = torch.from_numpy(data).cuda()
+        d_out = torch.zeros(ndzip_amd.compressed_length_bound(np.float32, shape), dtype=torch.int32, device="cuda")
+        d_len = torch.zeros(1, dtype=torch.int32, device="cuda")
+        comp.compress(d_in, shape, d_out, d_len)
+        comp.check()
+        n = int(d_len.cpu()[0])
+        assert np.array_equal(d_out[:n].cpu().numpy().view(np.uint32), oracle.compress(data))
+    with pytest.raises(ndzip_amd.NdzipHipError):
+        comp.compress(d_in, (64 * 4, 64 * 4), d_out, d_len)
+    with pytest.raises(ndzip_amd.NdzipHipError, match="dimensionality"):
+        comp.compress(d_in, (4096,), d_out, d_len)

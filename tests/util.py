@@ -1,0 +1,94 @@
+"""Shared helpers for the parity tests (inputs, device round trips through the C ABI)."""
+from __future__ import annotations
+
+import numpy as np
+
+SIDE = {1: 4096, 2: 64, 3: 16}
+PROFILES = [(np.float32, 1), (np.float32, 2), (np.float32, 3), (np.float64, 1), (np.float64, 2), (np.float64, 3)]
+
+
+def profile_id(p):
+    return f"{np.dtype(p[0]).name}-{p[1]}d"
+
+
+def word_dtype(dtype):
+    return np.uint32 if np.dtype(dtype).itemsize == 4 else np.uint64
+
+
+def random_unit_floats(shape, dtype, seed=0):
+    """Analogue of the reference's make_random_vector<float|double> (src/test/test_utils.hh:17-29): uniform [0,1)."""
+    rng = np.random.default_rng(seed)
+    return rng.random(size=shape, dtype=np.float64).astype(dtype)
+
+
+def random_bits(shape, dtype, seed=0):
+    """Uniform random bit patterns (includes NaN/Inf/denormal encodings), reinterpreted as `dtype`."""
+    rng = np.random.default_rng(seed)
+    w = word_dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64))
+    bits = rng.integers(0, np.iinfo(w).max, size=n, dtype=w, endpoint=True)
+    return bits.view(dtype).reshape(shape)
+
+
+def sparse_residuals(dtype, seed=0):
+    """The crafted residual pattern of src/test/codec_profile_test.inl:561-567: random words with selected
+    bit columns and selected rows of every chunk cleared."""
+    w = word_dtype(dtype)
+    bits = np.dtype(w).itemsize * 8
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, np.iinfo(w).max, size=4096, dtype=w, endpoint=True)
+    for i in range(4096):
+        for idx in (0, 12, 13, 29, bits - 2):
+            x[i] &= ~(w(1) << w((idx * (i // bits)) % bits))
+            x[i // bits * bits + idx] = 0
+    return x
+
+
+def device_compress(data: np.ndarray, device="cuda:0"):
+    """compress through the device-pointer C ABI; returns the stream (numpy words)."""
+    import torch
+
+    import ndzip_amd
+
+    data = np.ascontiguousarray(data)
+    extent = data.shape
+    bound = ndzip_amd.compressed_length_bound(data.dtype, extent)
+    wdt = torch.int32 if data.dtype == np.float32 else torch.int64
+    d_in = torch.from_numpy(data.reshape(-1).view(word_dtype(data.dtype)).view(np.int32 if data.dtype == np.float32 else np.int64)).to(device)
+    d_out = torch.zeros(max(1, bound), dtype=wdt, device=device)
+    d_len = torch.zeros(1, dtype=torch.int32, device=device)
+    comp = ndzip_amd.make_hip_compressor(data.dtype, ndzip_amd.CompressorRequirements(extent), torch.cuda.current_stream().cuda_stream)
+    comp.compress(d_in, extent, d_out, d_len)
+    comp.check()
+    n = int(d_len.cpu().numpy().view(np.uint32)[0])
+    assert n <= bound
+    out = d_out[:n].cpu().numpy().view(word_dtype(data.dtype))
+    comp.close()
+    return out
+
+
+def device_decompress(stream: np.ndarray, dtype, extent, device="cuda:0"):
+    import torch
+
+    import ndzip_amd
+
+    stream = np.ascontiguousarray(stream)
+    n = int(np.prod(extent, dtype=np.int64))
+    wdt = torch.int32 if np.dtype(dtype) == np.float32 else torch.int64
+    d_stream = torch.from_numpy(stream.view(np.int32 if stream.dtype == np.uint32 else np.int64)).to(device)
+    if d_stream.numel() == 0:
+        d_stream = torch.zeros(1, dtype=wdt, device=device)
+    d_out = torch.zeros(max(1, n), dtype=wdt, device=device)
+    dec = ndzip_amd.make_hip_decompressor(dtype, len(extent), torch.cuda.current_stream().cuda_stream)
+    dec.decompress(d_stream, d_out, extent)
+    dec.check()
+    out = d_out[:n].cpu().numpy().view(dtype).reshape(extent)
+    dec.close()
+    return out
+
+
+def same_bits(a: np.ndarray, b: np.ndarray) -> bool:
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype.itemsize == b.dtype.itemsize and np.array_equal(
+        a.reshape(-1).view(word_dtype(a.dtype)), b.reshape(-1).view(word_dtype(b.dtype)))
