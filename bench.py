@@ -1,0 +1,307 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the ndzip block encode/decode path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run, one
+rank per GPU over RCCL).  One "step" = compress the synthetic grid, then decompress it again, with the input
+already resident in HBM.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): 3D float32 512x512x512 synthetic turbulence per GPU (SURVEY.md Appendix B
+generator, seed 1, noise_mask 0xff).  At N GPUs the grid is (512*N) x 512 x 512 cut into N z-slabs (weak scaling:
+per-GPU work fixed); the only exchange is the RCCL all-gather of one length per rank + the header all-gather
+(ndzip_amd/sharded.py).  `value` = uncompressed bytes that went through compress plus uncompressed bytes that
+came out of decompress, over all ranks, divided by the wall time of the K timed steps (max over ranks).
+
+Extra objects:
+  roofline      dominant kernel = compress_kernel<float,3>: algorithmic bytes (raw in + stream out) per launch over
+                the HIP-event duration of the launch on the stream it runs on; peak 8 TB/s (HBM3E spec).
+  cpu_baseline  this repo's OpenMP port of the reference CPU path (oracle/, bit-exact with the compiled
+                reference) timed on the host cores of the same box on the same grid; plus the genuine reference
+                serial path (oracle/_ref) on a z-slab sample as `cpu_reference_serial`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0        # measured float4 copy ceiling from the same guide
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--shape", type=str, default="512,512,512", help="per-GPU slab (dimension 0 is multiplied by --gpus)")
+    ap.add_argument("--dtype", type=str, default="float32", choices=["float32", "float64"])
+    ap.add_argument("--noise-mask", type=lambda s: int(s, 0), default=0xFF)
+    ap.add_argument("--smooth", action="store_true", help="highly compressible bookend (two low-frequency octaves)")
+    ap.add_argument("--data", type=str, default="synthetic", choices=["synthetic", "random", "zeros"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(host_grid, dims):
+    """OpenMP port on all host cores + the genuine serial reference on a bounded sample (rank 0, N = 1 only)."""
+    import numpy as np
+
+    from oracle import oracle
+
+    out = {}
+    threads = oracle.max_threads()
+    nbytes = host_grid.nbytes
+    # warm-up + timed reps (about 10-30 s of CPU work in total at the most)
+    oracle.compress(host_grid[: max(16, host_grid.shape[0] // 8)], threads)
+    t_c, t_d, reps = 0.0, 0.0, 0
+    stream = None
+    t_start = time.perf_counter()
+    while reps < 5 and (time.perf_counter() - t_start) < 20.0:
+        t0 = time.perf_counter()
+        stream = oracle.compress(host_grid, threads)
+        t1 = time.perf_counter()
+        back, _ = oracle.decompress(stream, host_grid.dtype, host_grid.shape, threads)
+        t2 = time.perf_counter()
+        t_c += t1 - t0
+        t_d += t2 - t1
+        reps += 1
+    assert np.array_equal(back.view(stream.dtype), host_grid.view(stream.dtype))
+    out["cpu_baseline"] = {
+        "value": round(2 * nbytes * reps / (t_c + t_d) / 1e9, 3),
+        "unit": "GB/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"full {'x'.join(map(str, host_grid.shape))} {host_grid.dtype} grid, {reps} reps compress+decompress, OpenMP port of the reference CPU codec (oracle/ndzip_oracle.c)",
+        "compress_GBps": round(nbytes * reps / t_c / 1e9, 3),
+        "decompress_GBps": round(nbytes * reps / t_d / 1e9, 3),
+    }
+    if oracle.have_ref():
+        sample = host_grid[: max(16, host_grid.shape[0] // 8)]  # 64 z-planes of the 512^3 grid = 64 MiB
+        t0 = time.perf_counter()
+        s = oracle.ref_compress(sample)
+        t1 = time.perf_counter()
+        oracle.ref_decompress(s, sample.dtype, sample.shape)
+        t2 = time.perf_counter()
+        out["cpu_reference_serial"] = {
+            "value": round(2 * sample.nbytes / (t2 - t0) / 1e9, 3),
+            "unit": "GB/s",
+            "cores": 1,
+            "kind": "reference",
+            "sample": f"first {sample.shape[0]} z-planes ({sample.nbytes >> 20} MiB), reference serial CPU path compiled from /root/reference (oracle/_ref)",
+            "compress_GBps": round(sample.nbytes / (t1 - t0) / 1e9, 3),
+            "decompress_GBps": round(sample.nbytes / (t2 - t1) / 1e9, 3),
+        }
+    return out
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ndzip_amd
+    from ndzip_amd.sharded import ShardedCodec
+    from ndzip_amd.synth import synth_torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    per_gpu = tuple(int(x) for x in args.shape.split(","))
+    dims = len(per_gpu)
+    np_dtype = np.dtype(args.dtype)
+    t_dtype = torch.float32 if np_dtype == np.float32 else torch.float64
+    global_extent = (per_gpu[0] * world,) + per_gpu[1:]
+    codec = ShardedCodec(np_dtype, global_extent, rank, world, device)
+    shard = codec.shard
+
+    # ---- synthetic input, generated directly in HBM (identical bits on every machine) ------------------------------
+    if args.data == "synthetic":
+        # the slab's values depend on the GLOBAL coordinates: generate with the global linear offset
+        full = None
+        n_local = int(np.prod(shard.extent))
+        local = synth_slab(synth_torch, global_extent, shard, t_dtype, device, args.noise_mask, args.smooth)
+    elif args.data == "random":
+        g = torch.Generator(device=device)
+        g.manual_seed(1234 + rank)
+        it = torch.int32 if np_dtype == np.float32 else torch.int64
+        local = torch.randint(-2 ** 31, 2 ** 31 - 1, shard.extent, dtype=torch.int32, device=device, generator=g).view(torch.float32) \
+            if np_dtype == np.float32 else torch.randint(-2 ** 62, 2 ** 62, shard.extent, dtype=it, device=device, generator=g).view(torch.float64)
+    else:
+        local = torch.zeros(shard.extent, dtype=t_dtype, device=device)
+    out = torch.empty_like(local)
+    raw_bytes_local = local.numel() * local.element_size()
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        codec.compress(local)
+        if ev:
+            ev[1].record()
+        codec.decompress(out)
+        if ev:
+            ev[2].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    codec.check()
+
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    codec.check()
+
+    t_comp = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps * 1e-3   # seconds per launch
+    t_decomp = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps * 1e-3
+
+    # ---- verification (outside the timed region): round trip is bit-exact; stream hash for the record ---------------
+    body_len = int(codec.body_len.cpu()[0]) & 0xFFFFFFFF
+    ok = True
+    if not args.no_verify:
+        ok = bool(torch.equal(out.view(torch.int32 if np_dtype == np.float32 else torch.int64),
+                              local.view(torch.int32 if np_dtype == np.float32 else torch.int64)))
+    stats = torch.tensor([elapsed, t_comp, t_decomp, float(body_len), float(ok)], dtype=torch.float64, device=device)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        mn = stats.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        elapsed, t_comp, t_decomp = float(mx[0]), float(mx[1]), float(mx[2])
+        total_body_words = float(sm[3])
+        ok = bool(mn[4] > 0.5)
+    else:
+        total_body_words = float(body_len)
+
+    if rank == 0:
+        wb = np_dtype.itemsize
+        nhc_total = ndzip_amd.num_hypercubes(global_extent)
+        raw_total = raw_bytes_local * world
+        stream_bytes_total = (ndzip_amd.header_words(np_dtype, nhc_total) + total_body_words) * wb
+        ratio = stream_bytes_total / raw_total
+        value = 2 * raw_total * args.steps / elapsed / 1e9
+        comp_gbps = raw_total / t_comp / 1e9
+        decomp_gbps = raw_total / t_decomp / 1e9
+        algo_bytes_per_launch = raw_bytes_local + stream_bytes_total / world   # per GPU: N read + C written
+        achieved = algo_bytes_per_launch / t_comp / 1e9
+        result = {
+            "metric": "compress + decompress GB/s (uncompressed) per GPU; % of HBM3E peak",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32" if wb == 4 else "u64",
+            "data": "synthetic" if args.data == "synthetic" else args.data,
+            "config": {
+                "workload": f"{dims}D {np_dtype.name} {'x'.join(map(str, global_extent))} synthetic turbulence "
+                            f"(Appendix-B generator seed 1, noise_mask {args.noise_mask:#x}{', smooth' if args.smooth else ''}); "
+                            f"{world} z-slab(s) of {'x'.join(map(str, per_gpu))}",
+                "hypercubes": nhc_total,
+                "compression_ratio": round(ratio, 4),
+                "step": "compress then decompress, inputs resident in HBM",
+                "parallelism": f"hypercube-range sharding x{world}" + (" (RCCL all-gather of offsets + header)" if world > 1 else ""),
+            },
+            "per_gpu": {
+                "compress_GBps": round(comp_gbps / world, 2),
+                "decompress_GBps": round(decomp_gbps / world, 2),
+                "compress_frac_of_hbm_peak": round(comp_gbps / world / HBM_PEAK_GBPS, 4),
+                "decompress_frac_of_hbm_peak": round(decomp_gbps / world / HBM_PEAK_GBPS, 4),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": f"compress_kernel<{'float' if wb == 4 else 'double'},{dims}>",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
+                "launch_ms": round(t_comp * 1e3, 4),
+                "decompress": {
+                    "achieved": round(algo_bytes_per_launch / t_decomp / 1e9, 2),
+                    "frac": round(algo_bytes_per_launch / t_decomp / 1e9 / HBM_PEAK_GBPS, 4),
+                    "launch_ms": round(t_decomp * 1e3, 4),
+                },
+            },
+            "roundtrip_bit_exact": ok,
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                with open(traffic_file) as f:
+                    tr = json.load(f)
+                key = f"{np_dtype.name}-{'x'.join(map(str, per_gpu))}"
+                if key in tr:
+                    result["roofline"]["traffic"] = tr[key]["compress_hbm_bytes_per_launch"]
+                    result["roofline"]["traffic_source"] = tr[key].get("source")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result.update(cpu_baseline(local.cpu().numpy(), dims))
+            except Exception as e:  # the checker is optional for the GPU number, never the other way round
+                result["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("round trip mismatch")
+
+
+def synth_slab(synth_torch, global_extent, shard, t_dtype, device, noise_mask, smooth):
+    """Generate this rank's z-slab of the global field (values depend on global coordinates and linear index)."""
+    import torch
+
+    if shard.start0 == 0 and shard.extent == tuple(global_extent):
+        return synth_torch(global_extent, t_dtype, seed=1, noise_mask=noise_mask, smooth=smooth, device=device)
+    # generate plane blocks of the global grid and keep only this slab
+    planes = shard.extent[0]
+    rest = tuple(global_extent[1:])
+    out = torch.empty(shard.extent, dtype=t_dtype, device=device)
+    from ndzip_amd.synth import synth_torch_range
+
+    per_plane = 1
+    for x in rest:
+        per_plane *= x
+    flat = out.view(-1)
+    synth_torch_range(global_extent, t_dtype, shard.start0 * per_plane, planes * per_plane, flat, seed=1,
+                      noise_mask=noise_mask, smooth=smooth)
+    return out
+
+
+if __name__ == "__main__":
+    main()

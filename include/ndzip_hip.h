@@ -94,6 +94,11 @@ NDZIP_HIP_API int ndzip_hip_compressor_compress_split(ndzip_hip_compressor *c, c
  * the handle's stream. */
 NDZIP_HIP_API int ndzip_hip_compressor_offset_header(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, uint32_t base);
 
+/* Same with the base read from device memory (*d_base) when the kernel runs, so the offset exchange of the
+ * multi-GPU path needs no host synchronisation. */
+NDZIP_HIP_API int ndzip_hip_compressor_offset_header_device(
+        ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, const uint32_t *d_base);
+
 /* Reads and clears the handle's sticky device error word; synchronises the handle's stream. */
 NDZIP_HIP_API int ndzip_hip_compressor_check(ndzip_hip_compressor *c);
 
@@ -108,9 +113,11 @@ NDZIP_HIP_API int ndzip_hip_decompressor_decompress(
         ndzip_hip_decompressor *d, const void *d_stream, void *d_out, int dims, const uint32_t *extent);
 
 /* Split-buffer variant matching ndzip_hip_compressor_compress_split: `d_header` holds this extent's
- * num_hypercubes offset_after entries minus `header_base` (the global offset of `d_body`'s first word). */
+ * num_hypercubes global offset_after entries; `d_header_base` points to a DEVICE uint32 holding the global
+ * offset of `d_body`'s first word (NULL = 0).  For shard r > 0 that is simply the address of the previous
+ * shard's last header entry, so no host synchronisation is needed. */
 NDZIP_HIP_API int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uint32_t *d_header,
-        uint32_t header_base, const void *d_body, void *d_out, int dims, const uint32_t *extent);
+        const uint32_t *d_header_base, const void *d_body, void *d_out, int dims, const uint32_t *extent);
 
 NDZIP_HIP_API int ndzip_hip_decompressor_check(ndzip_hip_decompressor *d);
 NDZIP_HIP_API int ndzip_hip_decompressor_destroy(ndzip_hip_decompressor *d);

@@ -83,9 +83,9 @@ int check_limits(int dtype, const grid_geom &gg) {
 // ---- border gather/scatter (reference: compact_border / expand_border, cuda_codec.inl:463-474, :495-504) ------
 
 template<typename W, bool Pack>
-__global__ void border_kernel(W *data, W *body, const uint32_t *header, uint32_t nhc, uint32_t header_base, border_geom bg,
+__global__ void border_kernel(W *data, W *body, const uint32_t *header, uint32_t nhc, const uint32_t *header_base, border_geom bg,
         uint32_t *out_len, uint32_t len_extra) {
-    const uint64_t start = nhc ? header[nhc - 1] - header_base : 0u;  // stream<Profile>::border(), common.hh:365
+    const uint64_t start = nhc ? header[nhc - 1] - (header_base ? *header_base : 0u) : 0u;  // stream<Profile>::border(), common.hh:365
     W *border = body + start;
     const uint64_t zpart = bg.cz * bg.per_z;
     const uint64_t tails = bg.cy * bg.tail;
@@ -118,8 +118,13 @@ __global__ void offset_header_kernel(uint32_t *header, uint32_t count, uint32_t 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += base;
 }
 
+__global__ void offset_header_device_kernel(uint32_t *header, uint32_t count, const uint32_t *base) {
+    const uint32_t b = *base;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += b;
+}
+
 template<bool Pack>
-hipError_t launch_border(int dtype, void *data, void *body, const uint32_t *header, uint32_t nhc, uint32_t header_base,
+hipError_t launch_border(int dtype, void *data, void *body, const uint32_t *header, uint32_t nhc, const uint32_t *header_base,
         const border_geom &bg, uint32_t *out_len, uint32_t len_extra, hipStream_t stream) {
     if (bg.count == 0) {
         if (Pack && out_len && nhc == 0) hipLaunchKernelGGL(store_length_kernel, dim3(1), dim3(1), 0, stream, out_len, len_extra);
@@ -259,7 +264,7 @@ static int compress_common(ndzip_hip_compressor *c, const void *d_in, int dims, 
     if (gg.nhc > 0) {
         HIP_TRY(c->dtype == NDZIP_HIP_F32 ? launch_compress<float>(dims, a) : launch_compress<double>(dims, a));
     }
-    HIP_TRY(launch_border<true>(c->dtype, const_cast<void *>(d_in), d_body, d_header, gg.nhc, 0, bg, d_len, len_extra, c->stream));
+    HIP_TRY(launch_border<true>(c->dtype, const_cast<void *>(d_in), d_body, d_header, gg.nhc, nullptr, bg, d_len, len_extra, c->stream));
     return NDZIP_HIP_OK;
 }
 
@@ -285,6 +290,16 @@ int ndzip_hip_compressor_offset_header(ndzip_hip_compressor *c, uint32_t *d_head
     uint32_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(offset_header_kernel, dim3(blocks), dim3(256), 0, c->stream, d_header, count, base);
+    HIP_TRY(hipGetLastError());
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_compressor_offset_header_device(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, const uint32_t *d_base) {
+    if (!c || (!d_header && count) || !d_base) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (count == 0) return NDZIP_HIP_OK;
+    uint32_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(offset_header_device_kernel, dim3(blocks), dim3(256), 0, c->stream, d_header, count, d_base);
     HIP_TRY(hipGetLastError());
     return NDZIP_HIP_OK;
 }
@@ -321,7 +336,7 @@ int ndzip_hip_decompressor_create(int dtype, int dims, void *hip_stream, ndzip_h
     return NDZIP_HIP_OK;
 }
 
-int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uint32_t *d_header, uint32_t header_base,
+int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uint32_t *d_header, const uint32_t *header_base,
         const void *d_body, void *d_out, int dims, const uint32_t *extent) {
     if (!d || !extent || !d_body) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
@@ -353,7 +368,7 @@ int ndzip_hip_decompressor_decompress(ndzip_hip_decompressor *d, const void *d_s
     const uint32_t nhc = make_geom(dims, extent).nhc;
     const uint32_t hw = header_words_for(d->dtype, nhc);
     const void *body = static_cast<const char *>(d_stream) + static_cast<size_t>(hw) * word_bytes(d->dtype);
-    return ndzip_hip_decompressor_decompress_split(d, static_cast<const uint32_t *>(d_stream), 0, body, d_out, dims, extent);
+    return ndzip_hip_decompressor_decompress_split(d, static_cast<const uint32_t *>(d_stream), nullptr, body, d_out, dims, extent);
 }
 
 int ndzip_hip_decompressor_check(ndzip_hip_decompressor *d) {

@@ -28,7 +28,7 @@ struct compress_args {
 
 struct decompress_args {
     const uint32_t *header;   // NHC offset_after entries
-    uint32_t header_base;     // value the entries are relative to (0 for a whole stream; the global offset of
+    const uint32_t *header_base;  // device pointer to the value the entries are relative to (nullptr = 0; the global offset of
                               // `body`'s first word for a shard)
     const void *body;
     void *out;

@@ -179,7 +179,7 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
 
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads))
-decompress_kernel(const uint32_t *__restrict__ header, const uint32_t header_base, const typename word_of<T>::type *__restrict__ body,
+decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restrict__ header_base_ptr, const typename word_of<T>::type *__restrict__ body,
         typename word_of<T>::type *__restrict__ out, const grid_geom gg, uint32_t *err) {
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
@@ -197,6 +197,7 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t header_bas
     const bool active = hc < gg.nhc;
     uint32_t begin = 0, len = 0;
     if (active) {
+        const uint32_t header_base = header_base_ptr ? *header_base_ptr : 0u;
         begin = (hc ? header[hc - 1] : header_base) - header_base;  // stream<Profile>::hypercube, common.hh:350-358
         len = header[hc] - header_base - begin;
         if (len < static_cast<uint32_t>(P::head_words) || len > static_cast<uint32_t>(P::max_hc_words)) {

@@ -51,6 +51,7 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_compressor_compress",
     "ndzip_hip_compressor_compress_split",
     "ndzip_hip_compressor_offset_header",
+    "ndzip_hip_compressor_offset_header_device",
     "ndzip_hip_compressor_check",
     "ndzip_hip_compressor_destroy",
     "ndzip_hip_decompressor_create",
@@ -95,11 +96,12 @@ def lib():
     L.ndzip_hip_compressor_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _U32P, C.c_void_p, C.c_void_p]
     L.ndzip_hip_compressor_compress_split.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _U32P, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ndzip_hip_compressor_offset_header.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.ndzip_hip_compressor_offset_header_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ndzip_hip_compressor_check.argtypes = [C.c_void_p]
     L.ndzip_hip_compressor_destroy.argtypes = [C.c_void_p]
     L.ndzip_hip_decompressor_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.ndzip_hip_decompressor_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _U32P]
-    L.ndzip_hip_decompressor_decompress_split.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, _U32P]
+    L.ndzip_hip_decompressor_decompress_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _U32P]
     L.ndzip_hip_decompressor_check.argtypes = [C.c_void_p]
     L.ndzip_hip_decompressor_destroy.argtypes = [C.c_void_p]
     L.ndzip_hip_offload_compress.argtypes = [C.c_int, C.c_int, _U32P, C.c_void_p, C.c_void_p, _U32P, C.POINTER(C.c_uint64)]
@@ -217,6 +219,9 @@ class HipCompressor:
     def offset_header(self, device_header, count: int, base: int) -> None:
         _check(lib().ndzip_hip_compressor_offset_header(self._h, _ptr(device_header), count, base))
 
+    def offset_header_device(self, device_header, count: int, device_base) -> None:
+        _check(lib().ndzip_hip_compressor_offset_header_device(self._h, _ptr(device_header), count, _ptr(device_base)))
+
     def check(self) -> None:
         _check(lib().ndzip_hip_compressor_check(self._h))
 
@@ -245,8 +250,8 @@ class HipDecompressor:
     def decompress(self, in_device_stream, out_device_data, extent) -> None:
         _check(lib().ndzip_hip_decompressor_decompress(self._h, _ptr(in_device_stream), _ptr(out_device_data), len(extent), _ext(extent)))
 
-    def decompress_split(self, device_header, header_base: int, device_body, out_device_data, extent) -> None:
-        _check(lib().ndzip_hip_decompressor_decompress_split(self._h, _ptr(device_header), header_base, _ptr(device_body),
+    def decompress_split(self, device_header, device_header_base, device_body, out_device_data, extent) -> None:
+        _check(lib().ndzip_hip_decompressor_decompress_split(self._h, _ptr(device_header), _ptr(device_header_base), _ptr(device_body),
                                                               _ptr(out_device_data), len(extent), _ext(extent)))
 
     def check(self) -> None:

@@ -1,0 +1,195 @@
+"""Multi-GPU sharding of the block codec: one process per GPU, contiguous hypercube ranges per rank.
+
+The reference has no distributed runtime; this follows SURVEY.md section 8e:
+
+  * the slowest dimension is cut into `world` slabs whose thickness is a multiple of the hypercube side, so a
+    slab is a contiguous sub-array with a contiguous hypercube-index range and no halo;
+  * every rank compresses its slab with LOCAL offsets (ndzip_hip_compressor_compress_split);
+  * the only exchange is an all-gather of one body length per rank (-> exclusive prefix = the rank's global
+    word offset) and an all-gather of the header segments after the base has been added.  Bodies never move:
+    rank r's body lives at global body offset base_r, and the global stream is the concatenation
+    [header][body_0]...[body_{R-1}][border_0]...[border_{R-1}] -- a host/file-level operation outside the
+    timed region (`assemble_stream`), byte-identical to the single-GPU stream;
+  * decompression needs no collective: a rank decodes its slab from its header slice, its base and its body.
+
+The exchange is written against torch.distributed only, so the same code runs over RCCL (backend "nccl",
+device tensors) on the GPU box and over gloo (CPU tensors) in the world_size-2 CPU tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+SIDE = {1: 4096, 2: 64, 3: 16}
+
+
+@dataclass(frozen=True)
+class Shard:
+    rank: int
+    start0: int          # first index along dimension 0
+    extent: Tuple[int, ...]  # local extent (dimension 0 cut, others whole)
+    hc_begin: int        # global hypercube index range [hc_begin, hc_end)
+    hc_end: int
+    border: int          # local border element count
+
+    @property
+    def num_hypercubes(self) -> int:
+        return self.hc_end - self.hc_begin
+
+
+def plan_shards(extent: Sequence[int], world: int) -> List[Shard]:
+    """Cut dimension 0 into `world` slabs of whole hypercube planes; the last rank also takes the rows of
+    dimension 0 that no hypercube covers.  Hypercube order is row-major over the hypercube grid
+    (src/ndzip/common.hh:414-433), so a slab owns a contiguous index range."""
+    extent = tuple(int(x) for x in extent)
+    dims = len(extent)
+    side = SIDE[dims]
+    g = [e // side for e in extent]
+    per_plane = 1
+    for d in range(1, dims):
+        per_plane *= g[d]
+    whole_border = any(x == 0 for x in g)
+    shards = []
+    for r in range(world):
+        p0 = r * g[0] // world
+        p1 = (r + 1) * g[0] // world
+        start = p0 * side
+        stop = p1 * side if r + 1 < world else extent[0]
+        local = (stop - start,) + extent[1:]
+        n_local = 1
+        for x in local:
+            n_local *= x
+        nhc = 0 if whole_border else (p1 - p0) * per_plane
+        covered = nhc * 4096
+        shards.append(Shard(r, start, local, p0 * per_plane if not whole_border else 0,
+                            (p0 * per_plane if not whole_border else 0) + nhc, n_local - covered))
+    return shards
+
+
+def exchange_offsets(local_body_words, rank: int, world: int, group=None):
+    """All-gather one length per rank; returns (base, total, lengths) as tensors on the input's device:
+    base = sum of the lengths of lower ranks (this rank's global body word offset).  RCCL/gloo message:
+    world x 8 bytes."""
+    import torch
+    import torch.distributed as dist
+
+    mine = local_body_words.reshape(1).to(torch.int64)
+    if world == 1:
+        lens = mine.clone()
+    else:
+        lens = torch.empty(world, dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(lens, mine, group=group)
+    csum = torch.cumsum(lens, 0)
+    base = csum[rank] - lens[rank]
+    return base, csum[-1], lens
+
+
+def wrap_u32_to_i32(x):
+    """uint32 value held in an int64 tensor -> the int32 tensor with the same bits (torch has no uint32 math)."""
+    import torch
+
+    v = x.reshape(1).to(torch.int64)
+    v = torch.where(v >= 2 ** 31, v - 2 ** 32, v)
+    return v.to(torch.int32)
+
+
+def gather_headers(local_header,shard_sizes: Sequence[int], world: int, group=None):
+    """All-gather the (already globalised) header segments into the full header on every rank.
+    local_header: int32 tensor with this rank's entries.  Unequal segments are padded to the maximum."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return local_header.clone()
+    m = max(shard_sizes)
+    if m == 0:
+        return local_header.clone()
+    if all(s == m for s in shard_sizes):
+        out = torch.empty(world * m, dtype=local_header.dtype, device=local_header.device)
+        dist.all_gather_into_tensor(out, local_header.contiguous(), group=group)
+        return out
+    padded = torch.zeros(m, dtype=local_header.dtype, device=local_header.device)
+    padded[: local_header.numel()] = local_header
+    out = torch.empty(world * m, dtype=local_header.dtype, device=local_header.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * m: r * m + shard_sizes[r]] for r in range(world)])
+
+
+class ShardedCodec:
+    """Per-rank driver of the sharded compress / decompress path on one GPU.
+
+    All buffers are allocated once; compress() and decompress() enqueue work on the current torch stream and
+    on the process group's stream only (no host synchronisation inside)."""
+
+    def __init__(self, dtype, global_extent: Sequence[int], rank: int, world: int, device, group=None):
+        import numpy as np
+        import torch
+
+        import ndzip_amd
+
+        self.np_dtype = np.dtype(dtype)
+        self.extent = tuple(int(x) for x in global_extent)
+        self.dims = len(self.extent)
+        self.rank, self.world, self.group = rank, world, group
+        self.device = device
+        self.shards = plan_shards(self.extent, world)
+        self.shard = self.shards[rank]
+        self.words_per_elem_t = torch.int32 if self.np_dtype.itemsize == 4 else torch.int64
+        stream = torch.cuda.current_stream(device).cuda_stream
+        self.compressor = ndzip_amd.make_hip_compressor(dtype, ndzip_amd.CompressorRequirements(self.shard.extent), stream)
+        self.decompressor = ndzip_amd.make_hip_decompressor(dtype, self.dims, stream)
+        nhc = self.shard.num_hypercubes
+        bound = ndzip_amd.compressed_length_bound(dtype, self.shard.extent) - ndzip_amd.header_words(dtype, nhc)
+        self.header_local = torch.zeros(max(1, nhc + 1), dtype=torch.int32, device=device)
+        self.body = torch.zeros(max(1, bound), dtype=self.words_per_elem_t, device=device)
+        self.body_len = torch.zeros(1, dtype=torch.int32, device=device)
+        self.base32 = torch.zeros(1, dtype=torch.int32, device=device)
+        self.header_global: Optional["torch.Tensor"] = None
+        self.base = None
+        self.total = None
+
+    def compress(self, local_in) -> None:
+        """local_in: this rank's slab (device tensor).  Afterwards: self.header_global (all NHC entries, global
+        offsets), self.body / self.body_len (resident body + local border), self.base (global word offset)."""
+        import torch
+
+        sh = self.shard
+        self.compressor.compress_split(local_in, sh.extent, self.header_local, self.body, self.body_len)
+        # body words without the local border: the border count is known analytically
+        body_only = self.body_len.to(torch.int64) - sh.border
+        self.base, self.total, self.lens = exchange_offsets(body_only, self.rank, self.world, self.group)
+        self.base32.copy_(wrap_u32_to_i32(self.base))
+        self.compressor.offset_header_device(self.header_local, sh.num_hypercubes, self.base32)
+        sizes = [s.num_hypercubes for s in self.shards]
+        self.header_global = gather_headers(self.header_local[: sh.num_hypercubes], sizes, self.world, self.group)
+
+    def decompress(self, local_out) -> None:
+        """Decode this rank's slab from (global header slice, base, resident body).  The base stays on the
+        device: it is this rank's `base32` word (== the previous shard's last header entry)."""
+        sh = self.shard
+        hdr = self.header_global[sh.hc_begin: sh.hc_end] if sh.num_hypercubes else self.header_local
+        self.decompressor.decompress_split(hdr, self.base32, self.body, local_out, sh.extent)
+
+    def check(self) -> None:
+        self.compressor.check()
+        self.decompressor.check()
+
+
+def assemble_stream(dtype, extent, header_global, bodies, body_lens, shards: Sequence[Shard]):
+    """Host-level concatenation into the reference's single stream (numpy; outside any timed region)."""
+    import numpy as np
+
+    wdt = np.uint32 if np.dtype(dtype).itemsize == 4 else np.uint64
+    nhc = sum(s.num_hypercubes for s in shards)
+    per = 1 if wdt == np.uint32 else 2
+    hw = (nhc + per - 1) // per
+    hdr = np.zeros(hw * per, dtype=np.uint32)
+    hdr[:nhc] = np.asarray(header_global, dtype=np.uint32)[:nhc]
+    parts = [hdr.view(wdt)]
+    borders = []
+    for s, body, n in zip(shards, bodies, body_lens):
+        body = np.asarray(body).view(wdt)
+        n = int(n)
+        parts.append(body[: n - s.border])
+        borders.append(body[n - s.border: n])
+    return np.concatenate(parts + borders)

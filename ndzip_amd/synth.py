@@ -63,18 +63,16 @@ def synth_numpy(shape, dtype=np.float32, seed: int = 1, noise_mask: int = 0xFF, 
     return v.astype(dt) * dt.type(2.0 ** -12)
 
 
-def synth_torch(shape, dtype, seed: int = 1, noise_mask: int = 0xFF, smooth: bool = False, device="cuda",
-                slab: int = 1 << 24):
-    """Same field generated on `device` with torch int64 arithmetic, in slabs so temporaries stay small."""
+def synth_torch_range(shape, dtype, start: int, count: int, out_flat, seed: int = 1, noise_mask: int = 0xFF,
+                      smooth: bool = False, slab: int = 1 << 24):
+    """Fill `out_flat[0:count]` with elements [start, start+count) (global row-major linear index) of the field of
+    global shape `shape`, with torch int64 arithmetic on out_flat's device, in slabs so temporaries stay small."""
     import torch
 
     shape = tuple(int(s) for s in shape)
     dims = len(shape)
     names = _coords_axes(shape)
-    n = 1
-    for s in shape:
-        n *= s
-    out = torch.empty(n, dtype=dtype, device=device)
+    device = out_flat.device
     strides = []
     acc = 1
     for s in reversed(shape):
@@ -82,9 +80,9 @@ def synth_torch(shape, dtype, seed: int = 1, noise_mask: int = 0xFF, smooth: boo
         acc *= s
     strides = list(reversed(strides))
     M = _M32
-    for start in range(0, n, slab):
-        stop = min(n, start + slab)
-        lin = torch.arange(start, stop, dtype=torch.int64, device=device)
+    for s0 in range(start, start + count, slab):
+        s1 = min(start + count, s0 + slab)
+        lin = torch.arange(s0, s1, dtype=torch.int64, device=device)
         coords = {}
         rem = lin
         for d in range(dims):
@@ -106,5 +104,19 @@ def synth_torch(shape, dtype, seed: int = 1, noise_mask: int = 0xFF, smooth: boo
         h = (h * 0x846CA68B) & M
         h = h ^ (h >> 16)
         v = q + (h & (noise_mask & M)) - 1400000
-        out[start:stop] = v.to(dtype) * (2.0 ** -12)
+        out_flat[s0 - start: s1 - start] = v.to(dtype) * (2.0 ** -12)
+    return out_flat
+
+
+def synth_torch(shape, dtype, seed: int = 1, noise_mask: int = 0xFF, smooth: bool = False, device="cuda",
+                slab: int = 1 << 24):
+    """Same field as synth_numpy, generated on `device`."""
+    import torch
+
+    shape = tuple(int(s) for s in shape)
+    n = 1
+    for s in shape:
+        n *= s
+    out = torch.empty(n, dtype=dtype, device=device)
+    synth_torch_range(shape, dtype, 0, n, out, seed, noise_mask, smooth, slab)
     return out.reshape(shape)
