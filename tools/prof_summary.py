@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 CSV output (kernel trace / counter collection) for the ndzip kernels only.
+
+usage: prof_summary.py <rocprof output dir> [name filter, default 'ndzip_hip']
+Prints, per kernel: dispatch count, average duration (kernel trace) and average value per dispatch of every
+counter (counter collection).  The raw CSVs hold thousands of torch dispatches from the input generator and
+are left on the GPU box; only this summary is committed under profiles/.
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(compress_kernel|decompress_kernel|border_kernel|debug_\w+|offset_header\w*|store_length\w*)<?([^>(]*)", name)
+    if m:
+        return (m.group(1) + "<" + m.group(2) + ">").replace("ndzip_hip::", "")
+    return name[:80]
+
+
+def main():
+    root = sys.argv[1]
+    filt = sys.argv[2] if len(sys.argv) > 2 else "ndzip_hip"
+    for path in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+        dur = defaultdict(list)
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                name = row.get("Kernel_Name", "")
+                if filt in name:
+                    dur[short(name)].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        print(f"# {os.path.relpath(path, root)}")
+        print(f"{'kernel':60s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
+        for k, v in sorted(dur.items()):
+            print(f"{k:60s} {len(v):6d} {sum(v) / len(v) / 1e3:10.2f} {min(v) / 1e3:10.2f} {max(v) / 1e3:10.2f}")
+    for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+        acc = defaultdict(lambda: defaultdict(list))
+        meta = {}
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                name = row.get("Kernel_Name", "")
+                if filt in name:
+                    k = short(name)
+                    acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    meta[k] = (row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"),
+                               row.get("Workgroup_Size"), row.get("Grid_Size"))
+        print(f"# {os.path.relpath(path, root)}")
+        for k in sorted(acc):
+            print(f"{k}  vgpr/agpr/sgpr/lds/wg/grid={meta[k]}")
+            for c, v in sorted(acc[k].items()):
+                print(f"    {c:28s} n={len(v):4d} avg={sum(v) / len(v):16.1f}")
+
+
+if __name__ == "__main__":
+    main()
