@@ -224,59 +224,77 @@ NDZIP_DEV W wave_inclusive_scan_w(W v, int lane) {
 // groups, which still take part in the barriers).
 // ---------------------------------------------------------------------------------------------------------
 
+// raw input of one work-item, held in registers between the global load and the LDS staging (this is what the
+// persistent compress kernel prefetches for the NEXT tile while the current one is being written out)
+template<typename W, bool Aligned>
+struct input_regs {
+    static constexpr int VE = 16 / sizeof(W);                  // values per 16-byte vector
+    static constexpr int NV = hc_size / VE / threads_per_hc;   // 8 (f32) / 16 (f64) vectors per work-item
+    vec16 v[Aligned ? NV : 1];
+    W s[Aligned ? 1 : vals_per_thread];
+};
+
+// phase 0a: issue the coalesced global loads of hypercube `origin` (nothing waits here)
 template<typename T, int Dims, bool Aligned>
-NDZIP_DEV void forward_transform_hypercube(const typename profile<T, Dims>::word *__restrict__ in, const grid_geom &gg,
-        uint64_t origin, bool active, char *cube, const char *zero, int t,
-        typename profile<T, Dims>::word (&r)[vals_per_thread]) {
+NDZIP_DEV void load_hypercube_regs(const typename profile<T, Dims>::word *__restrict__ in, const grid_geom &gg,
+        uint64_t origin, int t, input_regs<typename profile<T, Dims>::word, Aligned> &regs) {
+    using W = typename profile<T, Dims>::word;
+    using R = input_regs<W, Aligned>;
+    if constexpr (Aligned) {
+#pragma unroll
+        for (int i = 0; i < R::NV; ++i) {
+            const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * R::VE;
+            regs.v[i] = *reinterpret_cast<const vec16 *>(in + origin + local_offset<Dims>(gg, k));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < vals_per_thread; ++i) {
+            const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
+            regs.s[i] = in[origin + local_offset<Dims>(gg, k)];
+        }
+    }
+}
+
+// phase 0b: rotl1 and store to the padded LDS staging layout
+template<typename W, bool Aligned>
+NDZIP_DEV void stage_hypercube_regs(const input_regs<W, Aligned> &regs, char *cube, int t) {
+    using L = lds_layout<W>;
+    using R = input_regs<W, Aligned>;
+    if constexpr (Aligned) {
+#pragma unroll
+        for (int i = 0; i < R::NV; ++i) {
+            const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * R::VE;
+            vec16 r;
+            if constexpr (sizeof(W) == 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r.w[j] = rotl1(regs.v[i].w[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint64_t x = rotl1(static_cast<uint64_t>(regs.v[i].w[2 * j])
+                            | (static_cast<uint64_t>(regs.v[i].w[2 * j + 1]) << 32));
+                    r.w[2 * j] = static_cast<uint32_t>(x);
+                    r.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
+                }
+            }
+            lds_write16(cube + L::off(k), r);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < vals_per_thread; ++i) {
+            const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
+            *reinterpret_cast<W *>(cube + L::off(k)) = rotl1(regs.s[i]);
+        }
+    }
+}
+
+// phase 1: fused Lorenzo stencil out of the staged cube + complement_negative -> residuals r[32] of work-item t.
+// No barrier inside: the caller orders it after the staging writes and before the cube is overwritten.
+template<typename T, int Dims>
+NDZIP_DEV void stencil_residuals(const char *cube, const char *zero, int t, typename profile<T, Dims>::word (&r)[vals_per_thread]) {
     using P = profile<T, Dims>;
     using W = typename P::word;
     using L = lds_layout<W>;
-    constexpr int VE = 16 / sizeof(W);  // values per 16-byte vector
-
-    // ---- phase 0: coalesced global -> (rotl1) -> LDS -------------------------------------------------
-    if (active) {
-        if constexpr (Aligned) {
-            constexpr int NV = hc_size / VE / threads_per_hc;  // 8 (f32) / 16 (f64) vectors per work-item
-            vec16 v[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * VE;
-                v[i] = *reinterpret_cast<const vec16 *>(in + origin + local_offset<Dims>(gg, k));
-            }
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * VE;
-                vec16 r;
-                if constexpr (sizeof(W) == 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) r.w[j] = rotl1(v[i].w[j]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const uint64_t x = rotl1(static_cast<uint64_t>(v[i].w[2 * j])
-                                | (static_cast<uint64_t>(v[i].w[2 * j + 1]) << 32));
-                        r.w[2 * j] = static_cast<uint32_t>(x);
-                        r.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
-                    }
-                }
-                lds_write16(cube + L::off(k), r);
-            }
-        } else {
-            W v[vals_per_thread];
-#pragma unroll
-            for (int i = 0; i < vals_per_thread; ++i) {
-                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
-                v[i] = in[origin + local_offset<Dims>(gg, k)];
-            }
-#pragma unroll
-            for (int i = 0; i < vals_per_thread; ++i) {
-                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
-                *reinterpret_cast<W *>(cube + L::off(k)) = rotl1(v[i]);
-            }
-        }
-    }
-    __syncthreads();
-
     // ---- phase 1: fused Lorenzo stencil out of LDS -> residuals r[32] in registers ----------------------
     const uint32_t k0 = static_cast<uint32_t>(t) * 32u;
     const char *own = cube + L::off(k0);
@@ -318,6 +336,7 @@ NDZIP_DEV void forward_transform_hypercube(const typename profile<T, Dims>::word
             b[j] -= a[j];  // row y0+1 minus row y0
             a[j] -= p[j];  // row y0 minus row y0-1
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the z-1 rows from being fetched while p is still live
         {
             W a1[16], b1[16], p1[16];
             const char *below = z > 0 ? cube + L::off(k0 - 256) : zero;
@@ -340,42 +359,60 @@ NDZIP_DEV void forward_transform_hypercube(const typename profile<T, Dims>::word
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) r[j] = complement_negative(r[j]);
+}
 
+// phases 0+1 for one hypercube (stage tests and the simple path): load, stage, barrier, stencil, barrier
+template<typename T, int Dims, bool Aligned>
+NDZIP_DEV void forward_transform_hypercube(const typename profile<T, Dims>::word *__restrict__ in, const grid_geom &gg,
+        uint64_t origin, bool active, char *cube, const char *zero, int t,
+        typename profile<T, Dims>::word (&r)[vals_per_thread]) {
+    using W = typename profile<T, Dims>::word;
+    if (active) {
+        input_regs<W, Aligned> regs;
+        load_hypercube_regs<T, Dims, Aligned>(in, gg, origin, t, regs);
+        stage_hypercube_regs<W, Aligned>(regs, cube, t);
+    }
+    __syncthreads();
+    stencil_residuals<T, Dims>(cube, zero, t, r);
     __syncthreads();  // all stencil reads done: `cube` may now be overwritten with the encoded run
 }
 
-// phase 2 of encode: residuals r[32] of work-item t -> encoded run at cube[0 .. L), returns L
+// ---- phase 2 of encode, in three steps so a kernel can publish lengths before the planes are written ---------
+//
+// encoded_chunk: what one work-item contributes -- its chunk's head, plane words and plane count.
+//   f32: planes[0..31] = the 32 bit planes of its chunk (plane 0 = MSB plane).
+//   f64: lanes (2m, 2m+1) share chunk m.  The even lane holds values 0..31 of the chunk, which land in bits
+//        63..32 of every plane word (uint32 index 1 of the word), the odd lane values 32..63 (bits 31..0).
+//        planes[0..31] are this lane's half of planes 0..31 (built from the high halves of the values),
+//        planes[32..63] its half of planes 32..63 (low halves).
+template<int B>
+struct encoded_chunk {
+    uint32_t planes[B];
+    uint32_t head_hi;  // f64: bits 63..32 of the chunk head; f32: the head
+    uint32_t head_lo;  // f64: bits 31..0
+    uint32_t count;    // non-zero planes of the chunk (same on both lanes of an f64 pair)
+    uint32_t scan_in;  // what this work-item feeds into the chunk-offset scan (f64: only the even lane counts)
+};
+
+// 2a: head + in-register bit transpose (no LDS, no barrier)
 template<typename T, int Dims>
-NDZIP_DEV uint32_t encode_residuals(typename profile<T, Dims>::word (&r)[vals_per_thread], char *cube, uint32_t *xchg, int t) {
-    using P = profile<T, Dims>;
-    constexpr int B = P::B;
-    // ---- phase 2: head, in-register transpose, chunk-offset scan, compaction into LDS -------------------
-    const int lane = t & 63, wave = t >> 6;
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(cube);
-    uint32_t total;
+NDZIP_DEV void encode_chunk(typename profile<T, Dims>::word (&r)[vals_per_thread], int t, encoded_chunk<profile<T, Dims>::B> &c) {
+    constexpr int B = profile<T, Dims>::B;
     if constexpr (B == 32) {
         uint32_t head = 0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) head |= r[j];
-        transpose32(r);
-        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(head));
-        const uint32_t incl = wave_inclusive_scan(cnt, lane);
-        if (lane == 63) xchg[wave] = incl;
-        __syncthreads();
-        const uint32_t wave_base = wave ? xchg[0] : 0u;
-        total = P::head_words + xchg[0] + xchg[1];
-        uint32_t pos = P::head_words + wave_base + incl - cnt;
-        out32[t] = head;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (r[i] != 0) out32[pos++] = r[i];
-        }
+        for (int j = 0; j < 32; ++j) c.planes[j] = r[j];
+        transpose32(c.planes);
+        c.head_hi = head;
+        c.head_lo = 0;
+        c.count = static_cast<uint32_t>(__builtin_popcount(head));
+        c.scan_in = c.count;
     } else {
-        // f64: lanes (2m, 2m+1) share chunk m.  The even lane holds values 0..31 of the chunk (they land in
-        // bits 63..32 of every plane word), the odd lane values 32..63 (bits 31..0).  Plane i < 32 is built
-        // from the high halves of the values, plane i >= 32 from the low halves.
-        uint32_t hi[32], lo[32];
         uint64_t own_or = 0;
+        uint32_t(&hi)[32] = *reinterpret_cast<uint32_t(*)[32]>(&c.planes[0]);
+        uint32_t(&lo)[32] = *reinterpret_cast<uint32_t(*)[32]>(&c.planes[32]);
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             own_or |= r[j];
@@ -385,33 +422,59 @@ NDZIP_DEV uint32_t encode_residuals(typename profile<T, Dims>::word (&r)[vals_pe
         const uint64_t head = own_or | __shfl_xor(own_or, 1, 64);
         transpose32(hi);
         transpose32(lo);
-        const bool upper = (t & 1) == 0;  // this lane supplies bits 63..32 (uint32 index 1 of the word)
-        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcountll(head));
-        const uint32_t incl = wave_inclusive_scan(upper ? cnt : 0u, lane);
-        if (lane == 63) xchg[wave] = incl;
-        __syncthreads();
-        const uint32_t wave_base = wave ? xchg[0] : 0u;
-        total = P::head_words + xchg[0] + xchg[1];
-        // exclusive offset of this chunk: inclusive value at the odd lane already contains the pair's count
-        uint32_t pos = P::head_words + wave_base + incl - cnt;
-        const uint32_t half = upper ? 1u : 0u;
-        out32[2 * (t >> 1) + half] = upper ? static_cast<uint32_t>(head >> 32) : static_cast<uint32_t>(head);
-        const uint32_t head_hi = static_cast<uint32_t>(head >> 32), head_lo = static_cast<uint32_t>(head);
+        c.head_hi = static_cast<uint32_t>(head >> 32);
+        c.head_lo = static_cast<uint32_t>(head);
+        c.count = static_cast<uint32_t>(__builtin_popcountll(head));
+        c.scan_in = (t & 1) == 0 ? c.count : 0u;
+    }
+}
+
+// 2c: write head and non-zero planes.  `run` = first uint32 of this hypercube's encoded run in LDS, `chunk_excl` =
+// number of plane words of all earlier chunks of the hypercube.
+template<typename T, int Dims>
+NDZIP_DEV void write_chunk(const encoded_chunk<profile<T, Dims>::B> &c, uint32_t *run, uint32_t chunk_excl, int t) {
+    using P = profile<T, Dims>;
+    constexpr int B = P::B;
+    uint32_t pos = P::head_words + chunk_excl;
+    if constexpr (B == 32) {
+        run[t] = c.head_hi;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            if ((head_hi >> (31 - i)) & 1u) {
-                out32[2 * pos + half] = hi[i];
+            if (c.planes[i] != 0) run[pos++] = c.planes[i];
+        }
+    } else {
+        const uint32_t half = (t & 1) == 0 ? 1u : 0u;  // even lane supplies bits 63..32 = uint32 index 1
+        run[2 * (t >> 1) + half] = half ? c.head_hi : c.head_lo;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if ((c.head_hi >> (31 - i)) & 1u) {
+                run[2 * pos + half] = c.planes[i];
                 ++pos;
             }
         }
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            if ((head_lo >> (31 - i)) & 1u) {
-                out32[2 * pos + half] = lo[i];
+            if ((c.head_lo >> (31 - i)) & 1u) {
+                run[2 * pos + half] = c.planes[32 + i];
                 ++pos;
             }
         }
     }
+}
+
+// residuals r[32] of work-item t -> encoded run at cube[0 .. L), returns L (one hypercube, 128 work-items)
+template<typename T, int Dims>
+NDZIP_DEV uint32_t encode_residuals(typename profile<T, Dims>::word (&r)[vals_per_thread], char *cube, uint32_t *xchg, int t) {
+    using P = profile<T, Dims>;
+    const int lane = t & 63, wave = t >> 6;
+    encoded_chunk<P::B> c;
+    encode_chunk<T, Dims>(r, t, c);
+    const uint32_t incl = wave_inclusive_scan(c.scan_in, lane);  // 2b: chunk offsets
+    if (lane == 63) xchg[wave] = incl;
+    __syncthreads();
+    const uint32_t total = P::head_words + xchg[0] + xchg[1];
+    // (for an f64 pair the inclusive value at the odd lane already contains the pair's count)
+    write_chunk<T, Dims>(c, reinterpret_cast<uint32_t *>(cube), (wave ? xchg[0] : 0u) + incl - c.count, t);
     __syncthreads();
     return total;
 }
@@ -644,9 +707,10 @@ namespace ndzip_hip {
 
 template<typename T, int Dims, bool Aligned>
 NDZIP_DEV void decode_hypercube(typename profile<T, Dims>::word *__restrict__ out, const grid_geom &gg, uint64_t origin,
-        bool active, char *cube, uint32_t *xchg, int t) {
+        bool active, char *cube, const char *run, uint32_t *xchg, int t) {
+    // `run`: first word of the encoded run inside `cube` (4-byte aligned; consumed before `cube` is overwritten)
     typename profile<T, Dims>::word r[vals_per_thread];
-    decode_residuals<T, Dims>(cube, xchg, t, r);
+    decode_residuals<T, Dims>(run, xchg, t, r);
     inverse_transform_hypercube<T, Dims, Aligned>(r, out, gg, origin, active, cube, xchg, t);
 }
 

@@ -31,7 +31,7 @@ struct tile_cfg {
     using W = typename word_of<T>::type;
     using L = lds_layout<W>;
     // resident workgroups per CU the LDS admits (160 KiB) -> wavefronts per SIMD the register budget must allow
-    static constexpr int min_waves_per_simd = 2;
+    static constexpr int min_waves_per_simd = sizeof(T) == 4 ? 3 : 2;
     static constexpr uint32_t xchg_bytes = 32;  // per hypercube: 2 x uint32 + 2 x W
     static constexpr uint32_t smem_bytes = K * L::cube_bytes + L::zero_bytes + K * xchg_bytes + 32;
 };
@@ -54,56 +54,69 @@ NDZIP_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// Decoupled look-back, executed by ONE wavefront.  Publishes this tile's aggregate, walks back over the
-// predecessors (nearest first, 256 per hop) until an inclusive prefix is found, publishes this tile's
-// inclusive prefix and returns its exclusive prefix.  Forward progress: the grid is persistent and fully
-// resident and every workgroup handles its tiles in increasing order, so the smallest unfinished tile never
-// waits.  Every spin is bounded; on timeout the error word is set and a partial (smaller) sum is returned,
-// which keeps all writes inside the caller's buffer.
-NDZIP_DEV uint32_t lookback_exclusive_prefix(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane) {
-    if (tile == 0) {
-        if (lane == 0) desc_store(desc, st_inclusive | aggregate);
-        return 0;
-    }
-    if (lane == 0) desc_store(desc + tile, st_aggregate | aggregate);
+// ---- decoupled look-back over tile lengths ---------------------------------------------------------------------
+// A tile publishes its length (aggregate) as soon as its chunk scan is done, keeps working, and only later
+// resolves its exclusive prefix by walking back over the predecessors (nearest first, 256 per hop) until a tile
+// with a known inclusive prefix is found.  Forward progress: the grid is persistent and fully resident and every
+// workgroup handles its tiles in increasing order, so the smallest unfinished tile never waits.  Every spin is
+// bounded; on timeout the error word is set and a partial (smaller) sum is returned, which keeps all writes
+// inside the caller's buffer.  While a predecessor is missing only ONE lane polls ONE descriptor (with s_sleep):
+// window-wide polling by a thousand workgroups would eat the memory system (MI355X guide, "polling-cost").
+
+NDZIP_DEV void publish_aggregate(tile_desc *desc, uint32_t tile, uint32_t aggregate) {
+    desc_store(desc + tile, (tile == 0 ? st_inclusive : st_aggregate) | aggregate);
+}
+
+NDZIP_DEV uint32_t resolve_exclusive_prefix(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane) {
+    if (tile == 0) return 0;
     uint32_t exclusive = 0;
     long long base = static_cast<long long>(tile) - 1;
     bool timed_out = false;
+    uint32_t spins = 0;
     for (;;) {
         tile_desc d[lookback_loads];
         bool found = false;
         int jf = 0, lf = 0;
-        for (uint32_t spins = 0;; ++spins) {
+        for (;;) {
 #pragma unroll
             for (int j = 0; j < lookback_loads; ++j) {
                 const long long idx = base - (j * 64 + lane);
                 d[j] = idx >= 0 ? desc_load(desc + idx) : st_inclusive;
             }
             found = false;
-            bool stall = false;
+            int wait_pos = -1;
 #pragma unroll
             for (int j = 0; j < lookback_loads; ++j) {
                 const uint32_t status = static_cast<uint32_t>(d[j] >> 32);
                 const unsigned long long invalid = __ballot(status == 0);
                 const unsigned long long inclusive = __ballot(status == 2);
-                if (!found) {
+                if (!found && wait_pos < 0) {
                     if (inclusive != 0) {
                         found = true;
                         jf = j;
                         lf = __builtin_ctzll(inclusive);
                         const unsigned long long nearer = lf == 0 ? 0ull : (~0ull >> (64 - lf));
-                        if (invalid & nearer) stall = true;
+                        if (invalid & nearer) wait_pos = j * 64 + __builtin_ctzll(invalid & nearer);
                     } else if (invalid != 0) {
-                        stall = true;
+                        wait_pos = j * 64 + __builtin_ctzll(invalid);
                     }
                 }
             }
-            if (!stall) break;
+            if (wait_pos < 0) break;
+            // the nearest missing predecessor: one lane polls it, then the window is read again
+            if (lane == 0) {
+                const tile_desc *p = desc + (base - wait_pos);
+                while (static_cast<uint32_t>(desc_load(p) >> 32) == 0 && spins < spin_limit) {
+                    __builtin_amdgcn_s_sleep(8);
+                    ++spins;
+                }
+            }
+            spins = __shfl(spins, 0, 64);
             if (spins >= spin_limit) {
                 timed_out = true;
+                found = false;
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
         }
         uint32_t s = 0;
 #pragma unroll
@@ -120,6 +133,28 @@ NDZIP_DEV uint32_t lookback_exclusive_prefix(tile_desc *desc, uint32_t tile, uin
     return exclusive;
 }
 
+// Coalesced copy of `n` words from LDS to global: scalar head up to the first 16-byte boundary of the
+// destination, 16-byte vector stores, scalar tail.  The LDS side is read word by word (its alignment relative
+// to the destination is arbitrary).
+template<typename W, int Threads>
+NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t n, int tid) {
+    constexpr uint32_t wpv = 16 / sizeof(W);
+    uint32_t lead = (wpv - static_cast<uint32_t>((reinterpret_cast<uintptr_t>(dst) / sizeof(W)) % wpv)) % wpv;
+    if (lead > n) lead = n;
+    if (static_cast<uint32_t>(tid) < lead) dst[tid] = src[tid];
+    const uint32_t nvec = (n - lead) / wpv;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src + lead);
+    vec16 *d16 = reinterpret_cast<vec16 *>(dst + lead);
+    for (uint32_t v = tid; v < nvec; v += Threads) {
+        vec16 x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x.w[j] = s32[4 * v + j];
+        d16[v] = x;
+    }
+    const uint32_t done = lead + nvec * wpv;
+    if (static_cast<uint32_t>(tid) < n - done) dst[done + tid] = src[done + tid];
+}
+
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (tile_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
@@ -127,53 +162,86 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
+    using P = profile<T, Dims>;
     constexpr int K = C::K;
+    constexpr int NW = C::threads / 64;            // wavefronts per workgroup (2 per hypercube)
+    constexpr uint32_t w32 = sizeof(W) / 4;        // uint32 per stream word
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x);
     const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
-    char *cube = smem + grp * L::cube_bytes;
+    const int lane = tid & 63, wave = tid >> 6;
+    char *cube = smem + grp * L::cube_bytes;        // staging of this group's hypercube
     char *zero = smem + K * L::cube_bytes;
-    uint32_t *xchg = reinterpret_cast<uint32_t *>(zero + L::zero_bytes) + grp * (C::xchg_bytes / 4);
-    uint32_t *tile_s = reinterpret_cast<uint32_t *>(zero + L::zero_bytes) + K * (C::xchg_bytes / 4);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);  // [0..NW) wave totals, [NW] tile prefix
+    uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);              // the K encoded runs, back to back
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero)[i] = 0;
-    // (the first barrier inside forward_transform_hypercube orders this before any stencil read)
+    // (ordered before the first stencil read by the barrier after staging)
 
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint32_t tile = blockIdx.x;
+    input_regs<W, Aligned> pre;
+    {
+        uint32_t first_hc = tile * K + grp;
+        if (first_hc >= gg.nhc) first_hc = gg.nhc - 1;
+        load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, first_hc), t, pre);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
         const uint32_t hc = tile * K + grp;
         const bool active = hc < gg.nhc;
-        const uint64_t origin = active ? hc_origin<Dims>(gg, hc) : 0;
-        uint32_t len = encode_hypercube<T, Dims, Aligned>(in, gg, origin, active, cube, zero, xchg, t);
-        if (!active) len = 0;
-        if (t == 0) tile_s[grp] = len;
+        if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
         __syncthreads();
-        if (tid < 64) {
-            uint32_t aggregate = 0;
+        W r[vals_per_thread];
+        stencil_residuals<T, Dims>(cube, zero, t, r);
+        __syncthreads();  // all stencil reads done: the staging region may now receive the encoded runs
+
+        encoded_chunk<P::B> c;
+        encode_chunk<T, Dims>(r, t, c);
+        const uint32_t incl = wave_inclusive_scan(active ? c.scan_in : 0u, lane);
+        if (lane == 63) misc[wave] = incl;
+        __syncthreads();
+        // lengths of the K hypercubes of this tile, known to every work-item
+        uint32_t run_start = 0, aggregate = 0, my_len = 0;
 #pragma unroll
-            for (int g = 0; g < K; ++g) aggregate += tile_s[g];
-            const uint32_t exclusive = lookback_exclusive_prefix(desc, tile, aggregate, err, tid);
-            if (tid == 0) tile_s[K] = exclusive;
+        for (int g = 0; g < K; ++g) {
+            const uint32_t len_g = tile * K + g < gg.nhc ? P::head_words + misc[2 * g] + misc[2 * g + 1] : 0u;
+            if (g < grp) run_start += len_g;
+            if (g == grp) my_len = len_g;
+            aggregate += len_g;
         }
-        __syncthreads();
-        uint32_t goff = tile_s[K];
-#pragma unroll
-        for (int g = 0; g < K; ++g) goff += g < grp ? tile_s[g] : 0u;
+        if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         if (active) {
-            const W *src = reinterpret_cast<const W *>(cube);
-            W *dst = body + goff;
-            for (uint32_t w = t; w < len; w += threads_per_hc) dst[w] = src[w];
-            if (t == 0) {
-                header[hc] = goff + len;  // offset_after(hc), common.hh:342-347
-                if (hc == gg.nhc - 1) {
-                    if (out_len) *out_len = len_extra + goff + len;
-                    // zero the header pad of 64-bit streams with an odd hypercube count (cuda_codec.inl:446-452)
-                    if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
-                }
+            write_chunk<T, Dims>(c, tile_run + run_start * w32, ((wave & 1) ? misc[2 * grp] : 0u) + incl - c.count, t);
+        }
+        // prefetch the next tile's input into registers; the loads fly while this tile is resolved and written out.
+        // (sched_barrier: do not let the scheduler hoist these loads above the plane writes -- the prefetch
+        // registers must not be live while the transposed planes are)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // Unconditional: a conditional load would keep the previous tile's registers live across the whole
+            // loop body.  Past the end the (valid, already cached) last hypercube is fetched again and ignored.
+            uint32_t next_hc = (tile + gridDim.x) * K + grp;
+            if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
+            load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < 64) {
+            const uint32_t exclusive = resolve_exclusive_prefix(desc, tile, aggregate, err, lane);
+            if (tid == 0) misc[NW] = exclusive;
+        }
+        __syncthreads();  // encoded runs complete in LDS, tile prefix known
+        const uint32_t prefix = misc[NW];
+        copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, aggregate, tid);
+        if (active && t == 0) {
+            header[hc] = prefix + run_start + my_len;  // offset_after(hc), common.hh:342-347
+            if (hc == gg.nhc - 1) {
+                if (out_len) *out_len = len_extra + prefix + run_start + my_len;
+                // zero the header pad of 64-bit streams with an odd hypercube count (cuda_codec.inl:446-452)
+                if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
             }
         }
-        __syncthreads();  // copy-out done before the next tile overwrites the staging buffers / tile_s
+        __syncthreads();  // copy-out has read the runs before the next tile is staged over them
     }
 }
 
@@ -205,16 +273,36 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
             len = 0;
         }
     }
-    W *dst = reinterpret_cast<W *>(cube);
+    // Load the encoded run with 16-byte vectors: start at the 16-byte boundary at or below the run's first word
+    // (never leaves the aligned block that holds valid stream words), so the run sits `mis` words into the LDS
+    // region.  All loads of a work-item are issued before the first one is consumed.
+    constexpr uint32_t wpv = 16 / sizeof(W);
+    constexpr int max_vec = (P::max_hc_words + wpv - 1 + wpv - 1) / wpv;            // run + worst misalignment
+    constexpr int vec_per_thread = (max_vec + threads_per_hc - 1) / threads_per_hc;   // 9 (f32) / 17 (f64)
+    uint32_t mis = 0;
     if (len == 0) {
         // padding group or corrupt entry: decode an all-zero hypercube so every LDS index stays in range
-        if (t < P::head_words) dst[t] = 0;
+        if (t < P::head_words) reinterpret_cast<W *>(cube)[t] = 0;
     } else {
         const W *src = body + begin;
-        for (uint32_t w = t; w < len; w += threads_per_hc) dst[w] = src[w];
+        mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(src) / sizeof(W)) % wpv);
+        const vec16 *src16 = reinterpret_cast<const vec16 *>(src - mis);
+        const uint32_t nvec = (len + mis + wpv - 1) / wpv;
+        vec16 v[vec_per_thread];
+#pragma unroll
+        for (int i = 0; i < vec_per_thread; ++i) {
+            const uint32_t j = static_cast<uint32_t>(i * threads_per_hc + t);
+            if (j < nvec) v[i] = src16[j];
+        }
+#pragma unroll
+        for (int i = 0; i < vec_per_thread; ++i) {
+            const uint32_t j = static_cast<uint32_t>(i * threads_per_hc + t);
+            if (j < nvec) lds_write16(cube + 16 * j, v[i]);
+        }
     }
     __syncthreads();
-    decode_hypercube<T, Dims, Aligned>(out, gg, active ? hc_origin<Dims>(gg, hc) : 0, active && len != 0, cube, xchg, t);
+    decode_hypercube<T, Dims, Aligned>(out, gg, active ? hc_origin<Dims>(gg, hc) : 0, active && len != 0, cube,
+            cube + mis * sizeof(W), xchg, t);
 }
 
 // ---- stage kernels for the parity tests: exactly one hypercube, 128 work-items ---------------------------------
