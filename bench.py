@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--data", type=str, default="synthetic", choices=["synthetic", "random", "zeros"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--compress-only", action="store_true", help="timing experiments: skip the decompress half of a step")
     return ap.parse_args()
 
 
@@ -155,14 +156,16 @@ def main():
         codec.compress(local)
         if ev:
             ev[1].record()
-        codec.decompress(out)
+        if not args.compress_only:
+            codec.decompress(out)
         if ev:
             ev[2].record()
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    codec.check()
+    if not args.compress_only:
+        codec.check()
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     if world > 1:
@@ -176,15 +179,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    codec.check()
+    if not args.compress_only:
+        codec.check()
 
     t_comp = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps * 1e-3   # seconds per launch
-    t_decomp = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps * 1e-3
+    t_decomp = max(1e-9, sum(e[1].elapsed_time(e[2]) for e in events) / args.steps * 1e-3)
 
     # ---- verification (outside the timed region): round trip is bit-exact; stream hash for the record ---------------
     body_len = int(codec.body_len.cpu()[0]) & 0xFFFFFFFF
     ok = True
-    if not args.no_verify:
+    if not args.no_verify and not args.compress_only:
         ok = bool(torch.equal(out.view(torch.int32 if np_dtype == np.float32 else torch.int64),
                               local.view(torch.int32 if np_dtype == np.float32 else torch.int64)))
     stats = torch.tensor([elapsed, t_comp, t_decomp, float(body_len), float(ok)], dtype=torch.float64, device=device)

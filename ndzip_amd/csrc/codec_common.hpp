@@ -58,6 +58,7 @@ struct grid_geom {
     uint32_t n[max_dims];       // extent (unused leading entries = 1)
     uint32_t g[max_dims];       // hypercube grid floor(n / side)
     uint64_t stride[max_dims];  // element strides
+    uint32_t g_magic[max_dims]; // floor(2^32 / g[d]) (0xffffffff for g = 1): division by g without a divider
     uint32_t nhc;               // num_hypercubes (common.hh:395-402)
     uint32_t dims;
 };
@@ -73,6 +74,7 @@ inline grid_geom make_geom(int dims, const uint32_t *extent) {
     for (int d = 0; d < max_dims; ++d) {
         gg.n[d] = d < dims ? extent[d] : 1;
         gg.g[d] = d < dims ? extent[d] / side : 1;
+        gg.g_magic[d] = gg.g[d] <= 1 ? 0xffffffffu : static_cast<uint32_t>((1ull << 32) / gg.g[d]);
         if (d < dims) gg.nhc *= gg.g[d];
     }
     uint64_t s = 1;

@@ -163,6 +163,17 @@ NDZIP_DEV void write_run16(char *p, const W (&src)[16]) {
 // hypercube <-> global addressing (common.hh:538-579)
 // ---------------------------------------------------------------------------------------------------------
 
+// n / d and n % d with the precomputed magic = floor(2^32 / d): the estimate mulhi(n, magic) is exact or one
+// too small, so a single correction step suffices (no v_rcp / integer-division expansion per tile).
+NDZIP_DEV void fast_divmod(uint32_t n, uint32_t d, uint32_t magic, uint32_t &q, uint32_t &r) {
+    q = __umulhi(n, magic);
+    r = n - q * d;
+    if (r >= d) {
+        ++q;
+        r -= d;
+    }
+}
+
 template<int Dims>
 NDZIP_DEV uint64_t hc_origin(const grid_geom &gg, uint32_t hc) {
     constexpr uint32_t side = side_of<Dims>::value;
@@ -170,8 +181,14 @@ NDZIP_DEV uint64_t hc_origin(const grid_geom &gg, uint32_t hc) {
 #pragma unroll
     for (int nd = 0; nd < Dims; ++nd) {
         const int d = Dims - 1 - nd;
-        const uint32_t c = hc % gg.g[d];
-        hc /= gg.g[d];
+        uint32_t c;
+        if (d == 0) {
+            c = hc;  // slowest dimension: nothing left to divide off
+        } else {
+            uint32_t q;
+            fast_divmod(hc, gg.g[d], gg.g_magic[d], q, c);
+            hc = q;
+        }
         off += static_cast<uint64_t>(c) * side * gg.stride[d];
     }
     return off;
@@ -240,17 +257,18 @@ NDZIP_DEV void load_hypercube_regs(const typename profile<T, Dims>::word *__rest
         uint64_t origin, int t, input_regs<typename profile<T, Dims>::word, Aligned> &regs) {
     using W = typename profile<T, Dims>::word;
     using R = input_regs<W, Aligned>;
+    // vector i of work-item t covers cube-local values k_i = (i*128 + t) * VE; 128*VE values are a whole number of
+    // rows / planes, so the global offset is affine in i: one per-lane base plus a uniform step.
     if constexpr (Aligned) {
+        const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
+        const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE);
 #pragma unroll
-        for (int i = 0; i < R::NV; ++i) {
-            const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * R::VE;
-            regs.v[i] = *reinterpret_cast<const vec16 *>(in + origin + local_offset<Dims>(gg, k));
-        }
+        for (int i = 0; i < R::NV; ++i) regs.v[i] = *reinterpret_cast<const vec16 *>(base + i * step);
     } else {
+        // scalar path for unaligned extents: 128 values are half a 3D plane, so the offset is NOT affine in i
 #pragma unroll
         for (int i = 0; i < vals_per_thread; ++i) {
-            const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
-            regs.s[i] = in[origin + local_offset<Dims>(gg, k)];
+            regs.s[i] = in[origin + local_offset<Dims>(gg, static_cast<uint32_t>(i * threads_per_hc + t))];
         }
     }
 }
@@ -327,28 +345,40 @@ NDZIP_DEV void stencil_residuals(const char *cube, const char *zero, int t, type
     } else {
         // chunk = rows (z, y0) and (z, y0 + 1): z = t / 8, y0 = 2 * (t % 8)
         const int z = t >> 3, yp = t & 7;
-        W a[16], b[16], p[16];
+        // Rows are fetched and folded in small groups with scheduling barriers in between: left alone the
+        // scheduler issues all 24 ds_read_b128 up front, which costs ~70 extra VGPRs and a wavefront of occupancy.
+        W a[16], b[16];
         read_run16<W>(own, a);
         read_run16<W>(own + 16 * sizeof(W), b);
-        read_run16<W>(yp > 0 ? cube + L::off(k0 - 16) : zero, p);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            b[j] -= a[j];  // row y0+1 minus row y0
-            a[j] -= p[j];  // row y0 minus row y0-1
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the z-1 rows from being fetched while p is still live
+        for (int j = 0; j < 16; ++j) b[j] -= a[j];  // row y0+1 minus row y0
+        __builtin_amdgcn_sched_barrier(0);
         {
-            W a1[16], b1[16], p1[16];
+            W p[16];
+            read_run16<W>(yp > 0 ? cube + L::off(k0 - 16) : zero, p);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] -= p[j];  // row y0 minus row y0-1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            W a1[16];
             const char *below = z > 0 ? cube + L::off(k0 - 256) : zero;
             read_run16<W>(below, a1);
-            read_run16<W>(z > 0 ? below + 16 * sizeof(W) : zero, b1);
-            read_run16<W>((z > 0 && yp > 0) ? cube + L::off(k0 - 256 - 16) : zero, p1);
+            {
+                W b1[16];
+                read_run16<W>(z > 0 ? below + 16 * sizeof(W) : zero, b1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                b[j] -= b1[j] - a1[j];
-                a[j] -= a1[j] - p1[j];
+                for (int j = 0; j < 16; ++j) b[j] -= b1[j] - a1[j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                W p1[16];
+                read_run16<W>((z > 0 && yp > 0) ? cube + L::off(k0 - 256 - 16) : zero, p1);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[j] -= a1[j] - p1[j];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 15; j >= 1; --j) {
             r[j] = a[j] - a[j - 1];

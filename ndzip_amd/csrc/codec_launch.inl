@@ -9,6 +9,8 @@
 //   decompress_kernel  one tile per workgroup, header lookup -> LDS -> decode (replaces decompress_block :477-492).
 //   debug_stage_kernel single-hypercube stage entry points for the parity tests.
 
+#include <cstdlib>
+
 #include "codec_kernels.hpp"
 #include "codec_launch.hpp"
 
@@ -31,7 +33,7 @@ struct tile_cfg {
     using W = typename word_of<T>::type;
     using L = lds_layout<W>;
     // resident workgroups per CU the LDS admits (160 KiB) -> wavefronts per SIMD the register budget must allow
-    static constexpr int min_waves_per_simd = sizeof(T) == 4 ? 3 : 2;
+    static constexpr int min_waves_per_simd = sizeof(T) == 4 ? 4 : 2;
     static constexpr uint32_t xchg_bytes = 32;  // per hypercube: 2 x uint32 + 2 x W
     static constexpr uint32_t smem_bytes = K * L::cube_bytes + L::zero_bytes + K * xchg_bytes + 32;
 };
@@ -158,7 +160,8 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (tile_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
-        typename word_of<T>::type *__restrict__ body, tile_desc *desc, uint32_t *out_len, uint32_t len_extra, uint32_t *err) {
+        typename word_of<T>::type *__restrict__ body, tile_desc *desc, uint32_t *out_len, uint32_t len_extra, uint32_t *err,
+        const uint32_t exp_flags) {
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -211,7 +214,7 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
             aggregate += len_g;
         }
         if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
-        if (active) {
+        if (active && !(exp_flags & 4u)) {
             write_chunk<T, Dims>(c, tile_run + run_start * w32, ((wave & 1) ? misc[2 * grp] : 0u) + incl - c.count, t);
         }
         // prefetch the next tile's input into registers; the loads fly while this tile is resolved and written out.
@@ -227,12 +230,14 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
         }
         __builtin_amdgcn_sched_barrier(0);
         if (tid < 64) {
-            const uint32_t exclusive = resolve_exclusive_prefix(desc, tile, aggregate, err, lane);
+            // (exp_flags: timing experiments only, see tools/ablate.sh; 0 in production)
+            const uint32_t exclusive = (exp_flags & 1u) ? tile * static_cast<uint32_t>(K * P::max_hc_words)
+                                                        : resolve_exclusive_prefix(desc, tile, aggregate, err, lane);
             if (tid == 0) misc[NW] = exclusive;
         }
         __syncthreads();  // encoded runs complete in LDS, tile prefix known
         const uint32_t prefix = misc[NW];
-        copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, aggregate, tid);
+        if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, aggregate, tid);
         if (active && t == 0) {
             header[hc] = prefix + run_start + my_len;  // offset_after(hc), common.hh:342-347
             if (hc == gg.nhc - 1) {
@@ -376,12 +381,14 @@ hipError_t launch_compress_profile(const compress_args &a) {
         blocks_per_cu = api < by_lds ? api : by_lds;
         if (blocks_per_cu < 1) blocks_per_cu = 1;
     }
-    uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(blocks_per_cu);
+    static const uint32_t exp_flags = getenv("NDZIP_HIP_EXP") ? static_cast<uint32_t>(atoi(getenv("NDZIP_HIP_EXP"))) : 0u;
+    static const int exp_bpc = getenv("NDZIP_HIP_BPC") ? atoi(getenv("NDZIP_HIP_BPC")) : 0;
+    uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(exp_bpc > 0 && exp_bpc < blocks_per_cu ? exp_bpc : blocks_per_cu);
     if (grid > ntiles) grid = ntiles;
     hipError_t e = hipMemsetAsync(a.desc, 0, static_cast<size_t>(ntiles) * sizeof(tile_desc), a.stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), C::smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg,
-            a.header, static_cast<W *>(a.body), a.desc, a.out_len, a.len_extra, a.err);
+            a.header, static_cast<W *>(a.body), a.desc, a.out_len, a.len_extra, a.err, exp_flags);
     return hipGetLastError();
 }
 
