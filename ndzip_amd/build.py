@@ -19,6 +19,7 @@ ARCH = "gfx950"
 SOURCES = ["kernels_f32.hip", "kernels_f64.hip", "capi.hip"]
 HEADERS = ["codec_common.hpp", "codec_kernels.hpp", "codec_launch.hpp", "codec_launch.inl", "../../include/ndzip_hip.h"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("NDZIP_EXTRA_FLAGS", "").split()  # experiments only (tools/)
 
 
 def _stale(target: str, deps) -> bool:

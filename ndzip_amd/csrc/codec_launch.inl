@@ -9,6 +9,7 @@
 //   decompress_kernel  one tile per workgroup, header lookup -> LDS -> decode (replaces decompress_block :477-492).
 //   debug_stage_kernel single-hypercube stage entry points for the parity tests.
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "codec_kernels.hpp"
@@ -33,7 +34,12 @@ struct tile_cfg {
     using W = typename word_of<T>::type;
     using L = lds_layout<W>;
     // resident workgroups per CU the LDS admits (160 KiB) -> wavefronts per SIMD the register budget must allow
-    static constexpr int min_waves_per_simd = sizeof(T) == 4 ? 4 : 2;
+    static constexpr int min_waves_per_simd = sizeof(T) == 4 ? 3 : 2;
+#ifdef NDZIP_EXP_EARLY_PREFETCH
+    static constexpr bool early_prefetch = true;
+#else
+    static constexpr bool early_prefetch = false;
+#endif
     static constexpr uint32_t xchg_bytes = 32;  // per hypercube: 2 x uint32 + 2 x W
     static constexpr uint32_t smem_bytes = K * L::cube_bytes + L::zero_bytes + K * xchg_bytes + 32;
 };
@@ -157,11 +163,17 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
     if (static_cast<uint32_t>(tid) < n - done) dst[done + tid] = src[done + tid];
 }
 
+// Tiles are handed out dynamically: `num_classes` ticket counters (class = blockIdx % num_classes, ticket n of class c
+// is tile n * num_classes + c), so tile order == start order, a tile's predecessors were all started before it, and
+// the look-back never depends on co-residency, dispatch order or placement.  Several counters because one word
+// saturates at ~88 returning atomics per microsecond on this part and a 512^3 grid needs ~80 tickets per microsecond.
+constexpr uint32_t max_ticket_classes = 16;
+
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (tile_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
-        typename word_of<T>::type *__restrict__ body, tile_desc *desc, uint32_t *out_len, uint32_t len_extra, uint32_t *err,
-        const uint32_t exp_flags) {
+        typename word_of<T>::type *__restrict__ body, tile_desc *desc, uint32_t *tickets, const uint32_t num_classes,
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags) {
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -176,33 +188,57 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
     const int lane = tid & 63, wave = tid >> 6;
     char *cube = smem + grp * L::cube_bytes;        // staging of this group's hypercube
     char *zero = smem + K * L::cube_bytes;
-    uint32_t *misc = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);  // [0..NW) wave totals, [NW] tile prefix
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);              // the K encoded runs, back to back
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero)[i] = 0;
-    // (ordered before the first stencil read by the barrier after staging)
 
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
-    uint32_t tile = blockIdx.x;
+    const uint32_t cls = blockIdx.x % num_classes;
+    uint32_t *ticket_counter = tickets + cls;
+    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
+    __syncthreads();  // (also orders the zero block before the first stencil read)
+    uint32_t tile = misc[NW + 1] * num_classes + cls;
+
+#ifdef NDZIP_EXP_PHASE_TIMING
+    const bool timing = (exp_flags & 16u) != 0;
+    uint32_t ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t_prev = timing ? __builtin_readcyclecounter() : 0;
+#define NDZIP_PHASE(i)                                          \
+    if (timing) {                                               \
+        const uint64_t now_ = __builtin_readcyclecounter();     \
+        ticks[i] += static_cast<uint32_t>(now_ - t_prev);       \
+        t_prev = now_;                                          \
+    }
+#else
+#define NDZIP_PHASE(i)
+#endif
+
+    // Input of the tile about to be processed, prefetched into registers.  The loads are unconditional (a
+    // conditional load would keep the previous registers live across the whole loop): out-of-range hypercubes
+    // re-read the last one and the result is ignored.
     input_regs<W, Aligned> pre;
     {
         uint32_t first_hc = tile * K + grp;
         if (first_hc >= gg.nhc) first_hc = gg.nhc - 1;
         load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, first_hc), t, pre);
     }
-    for (; tile < ntiles; tile += gridDim.x) {
+    while (tile < ntiles) {
         const uint32_t hc = tile * K + grp;
         const bool active = hc < gg.nhc;
         if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
+        NDZIP_PHASE(0)  // wait for the prefetched loads + stage
         __syncthreads();
         W r[vals_per_thread];
         stencil_residuals<T, Dims>(cube, zero, t, r);
+        NDZIP_PHASE(1)  // barrier + stencil
         __syncthreads();  // all stencil reads done: the staging region may now receive the encoded runs
 
         encoded_chunk<P::B> c;
         encode_chunk<T, Dims>(r, t, c);
         const uint32_t incl = wave_inclusive_scan(active ? c.scan_in : 0u, lane);
         if (lane == 63) misc[wave] = incl;
+        NDZIP_PHASE(2)  // barrier + transpose + chunk scan
         __syncthreads();
         // lengths of the K hypercubes of this tile, known to every work-item
         uint32_t run_start = 0, aggregate = 0, my_len = 0;
@@ -213,29 +249,36 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
             if (g == grp) my_len = len_g;
             aggregate += len_g;
         }
-        if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
+        uint32_t next_ticket = 0;
+        if (tid == 0) {
+            publish_aggregate(desc, tile, aggregate);      // as early as possible: successors wait on this
+            next_ticket = atomicAdd(ticket_counter, 1u);   // latency hidden behind the plane writes
+        }
         if (active && !(exp_flags & 4u)) {
             write_chunk<T, Dims>(c, tile_run + run_start * w32, ((wave & 1) ? misc[2 * grp] : 0u) + incl - c.count, t);
         }
-        // prefetch the next tile's input into registers; the loads fly while this tile is resolved and written out.
-        // (sched_barrier: do not let the scheduler hoist these loads above the plane writes -- the prefetch
-        // registers must not be live while the transposed planes are)
+        if (tid == 0) misc[NW + 1] = next_ticket;
+        NDZIP_PHASE(3)  // barrier + publish + plane writes
+        __syncthreads();  // next ticket known to all; encoded runs complete in LDS
+        const uint32_t next_tile = misc[NW + 1] * num_classes + cls;
+        uint32_t next_hc = next_tile * K + grp;
+        if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
+        // The look-back wavefront resolves the prefix BEFORE it issues its share of the prefetch: vector loads
+        // return in order, so descriptor reads queued behind 8 KiB of prefetch would pay the full loaded-memory
+        // latency on every hop.  The other wavefronts start their prefetch right away.
         __builtin_amdgcn_sched_barrier(0);
-        {
-            // Unconditional: a conditional load would keep the previous tile's registers live across the whole
-            // loop body.  Past the end the (valid, already cached) last hypercube is fetched again and ignored.
-            uint32_t next_hc = (tile + gridDim.x) * K + grp;
-            if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
-            load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (tid < 64) {
+        if (wave == 0) {
             // (exp_flags: timing experiments only, see tools/ablate.sh; 0 in production)
             const uint32_t exclusive = (exp_flags & 1u) ? tile * static_cast<uint32_t>(K * P::max_hc_words)
                                                         : resolve_exclusive_prefix(desc, tile, aggregate, err, lane);
             if (tid == 0) misc[NW] = exclusive;
         }
-        __syncthreads();  // encoded runs complete in LDS, tile prefix known
+        NDZIP_PHASE(4)  // look-back (wave 0)
+        __builtin_amdgcn_sched_barrier(0);
+        load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
+        __builtin_amdgcn_sched_barrier(0);
+        NDZIP_PHASE(5)  // prefetch issue
+        __syncthreads();  // tile prefix known
         const uint32_t prefix = misc[NW];
         if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, aggregate, tid);
         if (active && t == 0) {
@@ -246,8 +289,20 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
                 if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
             }
         }
+        NDZIP_PHASE(6)  // barrier + copy-out + header
         __syncthreads();  // copy-out has read the runs before the next tile is staged over them
+        NDZIP_PHASE(7)  // final barrier
+        tile = next_tile;
     }
+#undef NDZIP_PHASE
+#ifdef NDZIP_EXP_PHASE_TIMING
+    if (timing && tid == 0) {
+        unsigned long long *acc = desc + ntiles;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
+        atomicAdd(acc + 8, 1ull);
+    }
+#endif
 }
 
 template<typename T, int Dims, bool Aligned>
@@ -385,10 +440,24 @@ hipError_t launch_compress_profile(const compress_args &a) {
     static const int exp_bpc = getenv("NDZIP_HIP_BPC") ? atoi(getenv("NDZIP_HIP_BPC")) : 0;
     uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(exp_bpc > 0 && exp_bpc < blocks_per_cu ? exp_bpc : blocks_per_cu);
     if (grid > ntiles) grid = ntiles;
-    hipError_t e = hipMemsetAsync(a.desc, 0, static_cast<size_t>(ntiles) * sizeof(tile_desc), a.stream);
+    // scratch layout: [ntiles descriptors][16 x u64 experiment counters][max_ticket_classes x u32 ticket counters]
+    hipError_t e = hipMemsetAsync(a.desc, 0, (static_cast<size_t>(ntiles) + 16 + max_ticket_classes / 2) * sizeof(tile_desc), a.stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), C::smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg,
-            a.header, static_cast<W *>(a.body), a.desc, a.out_len, a.len_extra, a.err, exp_flags);
+            a.header, static_cast<W *>(a.body), a.desc, reinterpret_cast<uint32_t *>(a.desc + ntiles + 16),
+            grid >= max_ticket_classes ? max_ticket_classes : 1u, a.out_len, a.len_extra, a.err, exp_flags);
+    if (exp_flags & 16u) {  // experiments only: dump the per-phase cycle totals of this launch
+        unsigned long long acc[9];
+        (void) hipStreamSynchronize(a.stream);
+        (void) hipMemcpy(acc, a.desc + ntiles, sizeof acc, hipMemcpyDeviceToHost);
+        static int dumps = 0;
+        if (dumps++ % 8 == 4) {
+            const double n = static_cast<double>(acc[8] ? acc[8] : 1) * ((ntiles + grid - 1) / grid);
+            fprintf(stderr, "[phase ticks per iteration, avg over %llu workgroups]", acc[8]);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.0f", i, static_cast<double>(acc[i]) / n);
+            fprintf(stderr, "\n");
+        }
+    }
     return hipGetLastError();
 }
 
