@@ -115,7 +115,28 @@ struct alignas(16) vec16 {
     uint32_t w[4];
 };
 
-NDZIP_DEV vec16 lds_read16(const char *p) { return *reinterpret_cast<const vec16 *>(p); }
+// 16 bytes per lane from LDS as TWO 8-byte reads (the compiler fuses them into one ds_read2_b64).  Measured on
+// gfx950 (tools/ldsbench.hip, SQ_LDS_IDX_ACTIVE): ds_read2_b64 moves a wavefront's 1 KiB in 4 LDS cycles, a single
+// ds_read_b128 of the same bytes takes 16 -- with any lane stride, including the canonical contiguous one.
+struct alignas(8) vec8 {
+    uint32_t w[2];
+};
+NDZIP_DEV vec16 lds_read16(const char *p) {
+    // The LDS byte address is laundered through an empty asm so the compiler cannot prove 16-byte alignment and
+    // re-fuse the pair into one ds_read_b128; the explicit address-space casts keep it an LDS (ds_*) access.
+    using lds_char = const __attribute__((address_space(3))) char;
+    using lds_u64 = const __attribute__((address_space(3))) unsigned long long;
+    uint32_t a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_char *) p));
+    asm volatile("" : "+v"(a));
+    lds_u64 *q = reinterpret_cast<lds_u64 *>(static_cast<uintptr_t>(a));
+    const unsigned long long lo = q[0], hi = q[1];
+    vec16 v;
+    v.w[0] = static_cast<uint32_t>(lo);
+    v.w[1] = static_cast<uint32_t>(lo >> 32);
+    v.w[2] = static_cast<uint32_t>(hi);
+    v.w[3] = static_cast<uint32_t>(hi >> 32);
+    return v;
+}
 NDZIP_DEV void lds_write16(char *p, vec16 v) { *reinterpret_cast<vec16 *>(p) = v; }
 
 template<typename W>

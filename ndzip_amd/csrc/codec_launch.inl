@@ -35,10 +35,10 @@ struct tile_cfg {
     using L = lds_layout<W>;
     // resident workgroups per CU the LDS admits (160 KiB) -> wavefronts per SIMD the register budget must allow
     static constexpr int min_waves_per_simd = sizeof(T) == 4 ? 3 : 2;
-#ifdef NDZIP_EXP_EARLY_PREFETCH
-    static constexpr bool early_prefetch = true;
+#ifdef NDZIP_EXP_LOOKBACK_FIRST
+    static constexpr bool lookback_before_prefetch = true;
 #else
-    static constexpr bool early_prefetch = false;
+    static constexpr bool lookback_before_prefetch = false;
 #endif
     static constexpr uint32_t xchg_bytes = 32;  // per hypercube: 2 x uint32 + 2 x W
     static constexpr uint32_t smem_bytes = K * L::cube_bytes + L::zero_bytes + K * xchg_bytes + 32;
@@ -46,7 +46,14 @@ struct tile_cfg {
 
 constexpr unsigned long long st_aggregate = 1ull << 32;
 constexpr unsigned long long st_inclusive = 2ull << 32;
-constexpr int lookback_loads = 4;  // descriptors per lane and hop: 256 predecessor tiles per hop
+// Look-back window: how many predecessor descriptors one hop reads (one per lane).  Every descriptor read is an
+// uncached 8-byte agent-scope load, i.e. its own fabric transaction: measured on 512^3 f32, 256 per hop costs 45 us
+// more kernel time than 64 per hop, 1024 per hop 170 us more (profiles/) -- narrow windows win.
+#ifndef NDZIP_LOOKBACK_LANES
+#define NDZIP_LOOKBACK_LANES 64
+#endif
+constexpr int lookback_lanes = NDZIP_LOOKBACK_LANES;
+constexpr unsigned long long st_skip = 3ull << 32;  // lanes outside the window
 constexpr uint32_t spin_limit = 1u << 20;
 
 NDZIP_DEV tile_desc desc_load(const tile_desc *p) {
@@ -75,40 +82,54 @@ NDZIP_DEV void publish_aggregate(tile_desc *desc, uint32_t tile, uint32_t aggreg
     desc_store(desc + tile, (tile == 0 ? st_inclusive : st_aggregate) | aggregate);
 }
 
-NDZIP_DEV uint32_t resolve_exclusive_prefix(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane) {
+// Phase stagger: all workgroups of a launch start in the same phase, and the ordered write-out keeps them within
+// one iteration of each other, so without help every CU alternates between "all resident workgroups load" and
+// "all compute" and HBM and the VALUs take turns idling.  Delaying workgroup b by (b / grid) of one iteration
+// spreads the phases; co-resident workgroups (b, b + 256, ...) then sit a fixed fraction of an iteration apart.
+NDZIP_DEV void stagger_start(uint32_t iteration_kcycles) {
+    if (iteration_kcycles == 0) return;
+    const uint64_t delay = static_cast<uint64_t>(iteration_kcycles) * 1024u * blockIdx.x / gridDim.x;
+    const uint64_t t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(4);
+}
+
+// first look-back window of `tile`, issued early so its latency hides behind other work (vector loads return in
+// order: issue this BEFORE any bulk load of the same wavefront)
+NDZIP_DEV tile_desc lookback_issue(const tile_desc *desc, uint32_t tile, int lane) {
+    const long long idx = static_cast<long long>(tile) - 1 - lane;
+    if (lane >= lookback_lanes) return st_skip;
+    return idx >= 0 ? desc_load(desc + idx) : st_inclusive;
+}
+
+template<bool Preloaded>
+NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane,
+        tile_desc d) {
     if (tile == 0) return 0;
     uint32_t exclusive = 0;
     long long base = static_cast<long long>(tile) - 1;
     bool timed_out = false;
     uint32_t spins = 0;
+    bool use_preloaded = Preloaded;
     for (;;) {
-        tile_desc d[lookback_loads];
         bool found = false;
-        int jf = 0, lf = 0;
+        int lf = 0;
         for (;;) {
-#pragma unroll
-            for (int j = 0; j < lookback_loads; ++j) {
-                const long long idx = base - (j * 64 + lane);
-                d[j] = idx >= 0 ? desc_load(desc + idx) : st_inclusive;
+            if (!use_preloaded) {
+                const long long idx = base - lane;
+                d = lane >= lookback_lanes ? st_skip : idx >= 0 ? desc_load(desc + idx) : st_inclusive;
             }
-            found = false;
+            use_preloaded = false;
+            const uint32_t status = static_cast<uint32_t>(d >> 32);
+            const unsigned long long invalid = __ballot(status == 0);
+            const unsigned long long inclusive = __ballot(status == 2);
+            found = inclusive != 0;
             int wait_pos = -1;
-#pragma unroll
-            for (int j = 0; j < lookback_loads; ++j) {
-                const uint32_t status = static_cast<uint32_t>(d[j] >> 32);
-                const unsigned long long invalid = __ballot(status == 0);
-                const unsigned long long inclusive = __ballot(status == 2);
-                if (!found && wait_pos < 0) {
-                    if (inclusive != 0) {
-                        found = true;
-                        jf = j;
-                        lf = __builtin_ctzll(inclusive);
-                        const unsigned long long nearer = lf == 0 ? 0ull : (~0ull >> (64 - lf));
-                        if (invalid & nearer) wait_pos = j * 64 + __builtin_ctzll(invalid & nearer);
-                    } else if (invalid != 0) {
-                        wait_pos = j * 64 + __builtin_ctzll(invalid);
-                    }
-                }
+            if (found) {
+                lf = __builtin_ctzll(inclusive);
+                const unsigned long long nearer = lf == 0 ? 0ull : (~0ull >> (64 - lf));
+                if (invalid & nearer) wait_pos = __builtin_ctzll(invalid & nearer);
+            } else if (invalid != 0) {
+                wait_pos = __builtin_ctzll(invalid);
             }
             if (wait_pos < 0) break;
             // the nearest missing predecessor: one lane polls it, then the window is read again
@@ -126,24 +147,46 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix(tile_desc *desc, uint32_t tile, uint
                 break;
             }
         }
-        uint32_t s = 0;
-#pragma unroll
-        for (int j = 0; j < lookback_loads; ++j) {
-            const bool take = !found || j < jf || (j == jf && lane <= lf);
-            s += take ? static_cast<uint32_t>(d[j]) : 0u;
-        }
-        exclusive += wave_sum(s);
+        const bool take = !found || lane <= lf;
+        exclusive += wave_sum(take ? static_cast<uint32_t>(d) : 0u);
         if (found || timed_out) break;
-        base -= 64 * lookback_loads;
+        base -= lookback_lanes;
     }
     if (timed_out && lane == 0) atomicOr(err, 1u);
     if (lane == 0) desc_store(desc + tile, st_inclusive | (exclusive + aggregate));
     return exclusive;
 }
 
-// Coalesced copy of `n` words from LDS to global: scalar head up to the first 16-byte boundary of the
-// destination, 16-byte vector stores, scalar tail.  The LDS side is read word by word (its alignment relative
-// to the destination is arbitrary).
+NDZIP_DEV uint32_t resolve_exclusive_prefix(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane) {
+    return resolve_exclusive_prefix_impl<false>(desc, tile, aggregate, err, lane, 0ull);
+}
+
+// Coalesced copy of `n` words from LDS (16-byte aligned `src`) to global: scalar head up to the first 16-byte
+// boundary of the destination, 16-byte vector stores, scalar tail.  The destination's alignment relative to the
+// LDS run is arbitrary (0..3 uint32), so every output vector straddles two aligned LDS vectors: both are read as
+// 16 bytes per lane (conflict-free across lanes; four ds_read_b32 at a 16-byte lane stride would be a 4-way bank
+// conflict) and the straddle is resolved by a wave-uniform switch.  Reads up to 16 bytes past the run (inside LDS).
+template<int S>
+NDZIP_DEV vec16 straddle(const vec16 &lo, const vec16 &hi) {
+    vec16 x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.w[j] = S + j < 4 ? lo.w[(S + j) & 3] : hi.w[(S + j) & 3];
+    return x;
+}
+
+template<int S, int Threads>
+NDZIP_DEV void copy_vectors(const vec16 *__restrict__ a, vec16 *__restrict__ d16, uint32_t nvec, int tid) {
+    const char *base = reinterpret_cast<const char *>(a);
+    for (uint32_t v = tid; v < nvec; v += Threads) {
+        const vec16 lo = lds_read16(base + 16 * v);  // ds_read2_b64, see lds_read16
+        if constexpr (S == 0) {
+            d16[v] = lo;
+        } else {
+            d16[v] = straddle<S>(lo, lds_read16(base + 16 * v + 16));
+        }
+    }
+}
+
 template<typename W, int Threads>
 NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t n, int tid) {
     constexpr uint32_t wpv = 16 / sizeof(W);
@@ -151,13 +194,13 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
     if (lead > n) lead = n;
     if (static_cast<uint32_t>(tid) < lead) dst[tid] = src[tid];
     const uint32_t nvec = (n - lead) / wpv;
-    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src + lead);
+    const vec16 *a = reinterpret_cast<const vec16 *>(src);
     vec16 *d16 = reinterpret_cast<vec16 *>(dst + lead);
-    for (uint32_t v = tid; v < nvec; v += Threads) {
-        vec16 x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x.w[j] = s32[4 * v + j];
-        d16[v] = x;
+    switch (lead * (sizeof(W) / 4)) {  // uint32 offset of the first vector inside its aligned LDS vector
+        case 0: copy_vectors<0, Threads>(a, d16, nvec, tid); break;
+        case 1: copy_vectors<1, Threads>(a, d16, nvec, tid); break;
+        case 2: copy_vectors<2, Threads>(a, d16, nvec, tid); break;
+        default: copy_vectors<3, Threads>(a, d16, nvec, tid); break;
     }
     const uint32_t done = lead + nvec * wpv;
     if (static_cast<uint32_t>(tid) < n - done) dst[done + tid] = src[done + tid];
@@ -263,10 +306,14 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
         const uint32_t next_tile = misc[NW + 1] * num_classes + cls;
         uint32_t next_hc = next_tile * K + grp;
         if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
-        // The look-back wavefront resolves the prefix BEFORE it issues its share of the prefetch: vector loads
-        // return in order, so descriptor reads queued behind 8 KiB of prefetch would pay the full loaded-memory
-        // latency on every hop.  The other wavefronts start their prefetch right away.
+        // Vector loads return in order, so descriptor reads queued behind this wavefront's own prefetch pay its full
+        // latency on the first hop.  Measured trade-off (profiles/): issuing the whole prefetch first
+        // still wins for the single-buffered kernel because the tile's loads then overlap the look-back wait.
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!C::lookback_before_prefetch) {
+            load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (wave == 0) {
             // (exp_flags: timing experiments only, see tools/ablate.sh; 0 in production)
             const uint32_t exclusive = (exp_flags & 1u) ? tile * static_cast<uint32_t>(K * P::max_hc_words)
@@ -275,8 +322,10 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
         }
         NDZIP_PHASE(4)  // look-back (wave 0)
         __builtin_amdgcn_sched_barrier(0);
-        load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C::lookback_before_prefetch) {
+            load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         NDZIP_PHASE(5)  // prefetch issue
         __syncthreads();  // tile prefix known
         const uint32_t prefix = misc[NW];
@@ -292,6 +341,185 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
         NDZIP_PHASE(6)  // barrier + copy-out + header
         __syncthreads();  // copy-out has read the runs before the next tile is staged over them
         NDZIP_PHASE(7)  // final barrier
+        tile = next_tile;
+    }
+#undef NDZIP_PHASE
+#ifdef NDZIP_EXP_PHASE_TIMING
+    if (timing && tid == 0) {
+        unsigned long long *acc = desc + ntiles;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
+        atomicAdd(acc + 8, 1ull);
+    }
+#endif
+}
+
+// ---- double-buffered variant (f32) ----------------------------------------------------------------------------------
+// The encoded runs of a tile go to a second LDS region Y, so a tile is written out ONE ITERATION LATER:
+//   * its look-back window is read asynchronously at the top of the next iteration and consumed after that
+//     iteration's stencil + transposes -- an in-launch hand-off on this part costs about the time the reading CU's own
+//     memory queue takes to drain (several microseconds under a streaming load), which is now hidden, and the
+//     predecessors have had a whole iteration to publish;
+//   * the next tile's input is prefetched a whole iteration ahead, so HBM stays busy during compute.
+// Price: X + Y = 70.6 KiB of LDS per workgroup -> 2 workgroups (8 wavefronts) per CU, each of them rarely stalled.
+template<typename T, int Dims>
+struct db_cfg {
+    using C = tile_cfg<T, Dims>;
+    using W = typename C::W;
+    using L = typename C::L;
+    static constexpr uint32_t x_bytes = C::K * L::cube_bytes;
+    static constexpr uint32_t y_bytes = C::K * profile<T, Dims>::max_hc_words * sizeof(W);
+    static constexpr uint32_t smem_bytes = x_bytes + y_bytes + L::zero_bytes + 64;
+};
+
+template<typename T, int Dims, bool Aligned>
+__global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), 2)
+compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
+        typename word_of<T>::type *__restrict__ body, tile_desc *desc, uint32_t *tickets, const uint32_t num_classes,
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags) {
+    using C = tile_cfg<T, Dims>;
+    using D = db_cfg<T, Dims>;
+    using W = typename C::W;
+    using L = typename C::L;
+    using P = profile<T, Dims>;
+    constexpr int K = C::K;
+    constexpr int NW = C::threads / 64;
+    constexpr uint32_t w32 = sizeof(W) / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = static_cast<int>(threadIdx.x);
+    const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
+    const int lane = tid & 63, wave = tid >> 6;
+    char *cube = smem + grp * L::cube_bytes;                                   // X: staging of this group's hypercube
+    uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem + D::x_bytes);     // Y: the K encoded runs, back to back
+    char *zero = smem + D::x_bytes + D::y_bytes;
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);      // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
+
+    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero)[i] = 0;
+    stagger_start(exp_flags >> 8);
+
+    const uint32_t ntiles = (gg.nhc + K - 1) / K;
+    const uint32_t cls = blockIdx.x % num_classes;
+    uint32_t *ticket_counter = tickets + cls;
+#ifdef NDZIP_EXP_STATIC
+    uint32_t tile = blockIdx.x;
+    (void) ticket_counter;
+#else
+    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
+    __syncthreads();
+    uint32_t tile = misc[NW + 1] * num_classes + cls;
+#endif
+
+#ifdef NDZIP_EXP_PHASE_TIMING
+    const bool timing = (exp_flags & 16u) != 0;
+    uint32_t ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t_prev = timing ? __builtin_readcyclecounter() : 0;
+#define NDZIP_PHASE(i)                                          \
+    if (timing) {                                               \
+        const uint64_t now_ = __builtin_readcyclecounter();     \
+        ticks[i] += static_cast<uint32_t>(now_ - t_prev);       \
+        t_prev = now_;                                          \
+    }
+#else
+#define NDZIP_PHASE(i)
+#endif
+    input_regs<W, Aligned> pre;
+    {
+        uint32_t first_hc = tile * K + grp;
+        if (first_hc >= gg.nhc) first_hc = gg.nhc - 1;
+        load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, first_hc), t, pre);
+    }
+    // the previous tile: encoded in Y, aggregate published, waiting for its prefix
+    bool have_prev = false;
+    uint32_t prev_tile = 0, prev_aggregate = 0, prev_end = 0;  // prev_end: end of this group's run within the tile
+    bool prev_active = false;
+    uint32_t prev_hc = 0;
+    for (;;) {
+        const bool have_cur = tile < ntiles;
+        if (!have_cur && !have_prev) break;
+        const uint32_t hc = tile * K + grp;
+        const bool active = have_cur && hc < gg.nhc;
+        if (have_cur) {
+#ifdef NDZIP_EXP_STATIC
+            if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
+#else
+            uint32_t next_ticket = 0;
+            if (tid == 0) next_ticket = atomicAdd(ticket_counter, 1u);
+            if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
+            if (tid == 0) misc[NW + 1] = next_ticket;
+#endif
+        }
+        NDZIP_PHASE(0)  // ticket + wait prefetch + stage
+        __syncthreads();  // B1: X staged, next ticket known
+#ifdef NDZIP_EXP_STATIC
+        const uint32_t next_tile = have_cur ? tile + gridDim.x : tile;
+#else
+        const uint32_t next_tile = have_cur ? misc[NW + 1] * num_classes + cls : tile;
+#endif
+        tile_desc window = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        if (have_prev && wave == 0) window = lookback_issue(desc, prev_tile, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        encoded_chunk<P::B> c;
+        uint32_t incl = 0;
+        if (have_cur) {
+            uint32_t next_hc = next_tile * K + grp;
+            if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
+            load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
+            __builtin_amdgcn_sched_barrier(0);
+            NDZIP_PHASE(1)  // B1 + window issue + prefetch issue
+            W r[vals_per_thread];
+            stencil_residuals<T, Dims>(cube, zero, t, r);
+            NDZIP_PHASE(2)  // stencil
+            encode_chunk<T, Dims>(r, t, c);
+            incl = wave_inclusive_scan(active ? c.scan_in : 0u, lane);
+            if (lane == 63) misc[wave] = incl;
+        }
+        NDZIP_PHASE(3)  // transposes + scan
+        __syncthreads();  // B2: wave totals known
+        uint32_t run_start = 0, aggregate = 0, my_len = 0;
+        if (have_cur) {
+#pragma unroll
+            for (int g = 0; g < K; ++g) {
+                const uint32_t len_g = tile * K + g < gg.nhc ? P::head_words + misc[2 * g] + misc[2 * g + 1] : 0u;
+                if (g < grp) run_start += len_g;
+                if (g == grp) my_len = len_g;
+                aggregate += len_g;
+            }
+            if (tid == 0) publish_aggregate(desc, tile, aggregate);
+        }
+        if (have_prev && wave == 0) {
+            const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
+                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
+            if (tid == 0) misc[NW] = exclusive;
+        }
+        NDZIP_PHASE(4)  // B2 + publish + resolve (wave 0)
+        __syncthreads();  // B3: prefix of the previous tile known
+        if (have_prev) {
+            const uint32_t prefix = misc[NW];
+            if (!(exp_flags & 2u)) {
+                copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
+            }
+            if (prev_active && t == 0) {
+                header[prev_hc] = prefix + prev_end;  // offset_after(hc), common.hh:342-347
+                if (prev_hc == gg.nhc - 1) {
+                    if (out_len) *out_len = len_extra + prefix + prev_end;
+                    if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
+                }
+            }
+        }
+        NDZIP_PHASE(5)  // B3 + copy-out
+        __syncthreads();  // B4: Y has been read, the current tile's runs may replace it
+        if (active && !(exp_flags & 4u)) {
+            write_chunk<T, Dims>(c, tile_run + run_start * w32, ((wave & 1) ? misc[2 * grp] : 0u) + incl - c.count, t);
+        }
+        NDZIP_PHASE(6)  // B4 + plane writes
+        have_prev = have_cur;
+        prev_tile = tile;
+        prev_aggregate = aggregate;
+        prev_end = run_start + my_len;
+        prev_active = active;
+        prev_hc = hc;
         tile = next_tile;
     }
 #undef NDZIP_PHASE
@@ -425,14 +653,19 @@ hipError_t launch_compress_profile(const compress_args &a) {
     using W = typename C::W;
     const uint32_t ntiles = (a.gg.nhc + C::K - 1) / C::K;
     if (ntiles == 0) return hipSuccess;
-    auto kernel = compress_kernel<T, Dims, Aligned>;
+    constexpr bool use_db = sizeof(T) == 4;  // double-buffered variant where X + Y still leaves 2 workgroups per CU
+    auto kernel = use_db ? compress_kernel_db<T, Dims, Aligned> : compress_kernel<T, Dims, Aligned>;
+    constexpr uint32_t smem_bytes = use_db ? db_cfg<T, Dims>::smem_bytes : C::smem_bytes;
     // persistent grid, fully resident: bounded by the occupancy query and by what the LDS alone admits
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int api = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel, C::threads, C::smem_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                static_cast<int>(smem_bytes));
         if (e != hipSuccess) return e;
-        const int by_lds = static_cast<int>((160u * 1024u) / C::smem_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel, C::threads, smem_bytes);
+        if (e != hipSuccess) return e;
+        const int by_lds = static_cast<int>((160u * 1024u) / smem_bytes);
         blocks_per_cu = api < by_lds ? api : by_lds;
         if (blocks_per_cu < 1) blocks_per_cu = 1;
     }
@@ -443,7 +676,7 @@ hipError_t launch_compress_profile(const compress_args &a) {
     // scratch layout: [ntiles descriptors][16 x u64 experiment counters][max_ticket_classes x u32 ticket counters]
     hipError_t e = hipMemsetAsync(a.desc, 0, (static_cast<size_t>(ntiles) + 16 + max_ticket_classes / 2) * sizeof(tile_desc), a.stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), C::smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg,
             a.header, static_cast<W *>(a.body), a.desc, reinterpret_cast<uint32_t *>(a.desc + ntiles + 16),
             grid >= max_ticket_classes ? max_ticket_classes : 1u, a.out_len, a.len_extra, a.err, exp_flags);
     if (exp_flags & 16u) {  // experiments only: dump the per-phase cycle totals of this launch
