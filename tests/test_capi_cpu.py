@@ -1,0 +1,89 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/ndzip_hip.h declares, its host-side sizing logic
+matches the oracle, and -- without a GPU -- every compute entry point fails loudly (there is no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import ndzip_amd
+from ndzip_amd import hip
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ndzip_hip.h")).read()
+    return sorted(set(re.findall(r"NDZIP_HIP_API[^;(]*?\b(ndzip_hip_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    assert sorted(hip.EXPORTED_SYMBOLS) == declared, "hip.py symbol table out of sync with include/ndzip_hip.h"
+    L = hip.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (ndzip_hip_\w+)", out))
+    assert exported == set(declared), f"unexpected exports: {exported ^ set(declared)}"
+
+
+def test_library_contains_gfx950_code_object():
+    out = subprocess.run(["strings", "-n", "6", hip.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sizing_matches_oracle(dtype):
+    shapes = [(0,), (1,), (5,), (4096,), (4099,), (12305,), (64, 64), (70, 200), (200, 131), (1, 4096), (16, 16, 16), (17, 35, 33),
+              (50, 37, 41), (3, 4, 15), (512, 512, 512), (8192, 8192), (2048, 1024, 1024)]
+    for shape in shapes:
+        assert ndzip_amd.compressed_length_bound(dtype, shape) == oracle.compressed_length_bound(dtype, shape)
+        assert ndzip_amd.num_hypercubes(shape) == oracle.num_hypercubes(shape)
+    for nhc in (0, 1, 2, 3, 32768):
+        assert ndzip_amd.header_words(dtype, nhc) == (nhc if dtype == np.float32 else (nhc + 1) // 2)
+
+
+def test_compressor_requirements_semantics():
+    """ndzip::compressor_requirements: max hypercubes over extents of one dimensionality (common.cc:8-28)"""
+    req = ndzip_amd.CompressorRequirements((64 * 3, 64 * 2), (64, 64 * 5))
+    assert req.dims == 2 and req.max_num_hypercubes == 6
+    with pytest.raises(RuntimeError, match="-dimensional"):
+        req.include((4096,))
+
+
+def test_invalid_arguments_are_rejected_on_the_host():
+    with pytest.raises(ndzip_amd.NdzipHipError):
+        ndzip_amd.compressed_length_bound(np.float32, (1, 2, 3, 4))
+    with pytest.raises(TypeError):
+        ndzip_amd.compressed_length_bound(np.int32, (16,))
+    with pytest.raises(ndzip_amd.NdzipHipError, match="[Dd]imensionality"):
+        ndzip_amd.make_hip_offloader(np.float32, 4)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(ndzip_amd.NdzipHipError) as e:
+        ndzip_amd.make_hip_offloader(np.float32, 1).compress(np.zeros(4096, np.float32))
+    assert e.value.status == hip.ERR_NO_DEVICE
+    with pytest.raises(ndzip_amd.NdzipHipError) as e:
+        ndzip_amd.make_hip_compressor(np.float32, ndzip_amd.CompressorRequirements((4096,)))
+    assert e.value.status == hip.ERR_NO_DEVICE
+    with pytest.raises(ndzip_amd.NdzipHipError):
+        ndzip_amd.device_info()
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under ndzip_amd/ or bench.py's product path may import it."""
+    for base, _, files in os.walk(os.path.join(ROOT, "ndzip_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".inl", ".h")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                for needle in ("import oracle", "from oracle", "libndzip_oracle", "ndzip_oracle_", "ndzip_ref_", "oracle/"):
+                    assert needle not in text, f"{f} references the oracle ({needle})"

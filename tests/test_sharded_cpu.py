@@ -1,0 +1,84 @@
+"""CPU suite for the multi-GPU path: shard planning and, with two gloo processes, the offset exchange +
+header gather.  The per-rank codec is the ORACLE here (this is a test of the host logic), the collectives are the very
+functions the GPU path uses (ndzip_amd.sharded.exchange_offsets / gather_headers / assemble_stream)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from ndzip_amd.sharded import SIDE, assemble_stream, plan_shards
+from ndzip_amd.synth import synth_numpy
+from oracle import oracle
+
+
+@pytest.mark.parametrize("extent,world", [((512, 512, 512), 8), ((2048, 1024, 1024), 8), ((1024, 1024, 1024), 8), ((8192, 8192), 8),
+                                          ((50, 37, 41), 3), ((70, 200), 2), ((12305,), 4), ((5,), 2), ((16, 16, 16), 4), ((100, 100), 3)])
+def test_plan_shards_partitions_hypercubes_and_elements(extent, world):
+    shards = plan_shards(extent, world)
+    assert len(shards) == world
+    assert sum(s.num_hypercubes for s in shards) == oracle.num_hypercubes(extent)
+    assert sum(s.border for s in shards) == oracle.border_count(extent)
+    assert sum(s.extent[0] for s in shards) == extent[0]
+    pos, hc = 0, 0
+    side = SIDE[len(extent)]
+    for s in shards:
+        assert s.start0 == pos and s.hc_begin == hc
+        assert s.extent[1:] == tuple(extent[1:])
+        if s.rank + 1 < world:
+            assert s.extent[0] % side == 0
+        assert s.num_hypercubes == oracle.num_hypercubes(s.extent) and s.border == oracle.border_count(s.extent)
+        pos += s.extent[0]
+        hc = s.hc_end
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, extent, dtype_name, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from ndzip_amd.sharded import exchange_offsets, gather_headers, wrap_u32_to_i32
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dtype = np.dtype(dtype_name)
+    wdt = np.uint32 if dtype.itemsize == 4 else np.uint64
+    full = synth_numpy(extent, dtype.type, seed=77, noise_mask=0xFF)
+    shards = plan_shards(extent, world)
+    sh = shards[rank]
+    local = np.ascontiguousarray(full[sh.start0: sh.start0 + sh.extent[0]])
+    # per-rank codec with LOCAL offsets (what ndzip_hip_compressor_compress_split produces): header + body(+border)
+    stream = oracle.compress(local)
+    nhc = sh.num_hypercubes
+    hw = (nhc + (1 if wdt == np.uint32 else 2) - 1) // (1 if wdt == np.uint32 else 2)
+    header_local = np.frombuffer(stream.tobytes(), dtype=np.uint32)[:nhc].copy()
+    body = stream[hw:]
+    body_only = torch.tensor([len(body) - sh.border], dtype=torch.int64)
+    base, total, lens = exchange_offsets(body_only, rank, world)
+    hdr = torch.from_numpy(header_local.view(np.int32)) + wrap_u32_to_i32(base)
+    header_global = gather_headers(hdr, [s.num_hypercubes for s in shards], world)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), header=header_global.numpy().view(np.uint32), body=body.view(wdt), base=int(base), total=int(total))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("extent,dtype", [((64, 48, 32), np.float32), ((130, 200), np.float64), ((50, 37, 41), np.float32), ((3 * 4096 + 5,), np.float64)])
+def test_two_rank_gloo_exchange_reproduces_single_stream(tmp_path, extent, dtype):
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = _free_port()
+    mp.spawn(_rank_main, args=(world, port, extent, np.dtype(dtype).name, str(tmp_path)), nprocs=world, join=True)
+    full = synth_numpy(extent, dtype, seed=77, noise_mask=0xFF)
+    want = oracle.compress(full)
+    shards = plan_shards(extent, world)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert np.array_equal(parts[0]["header"], parts[1]["header"]), "every rank must hold the same global header"
+    assert int(parts[0]["base"]) == 0 and int(parts[1]["base"]) == len(parts[0]["body"]) - shards[0].border
+    got = assemble_stream(dtype, extent, parts[0]["header"], [p["body"] for p in parts], [len(p["body"]) for p in parts], shards)
+    assert len(got) == len(want) and np.array_equal(got, want)
