@@ -148,13 +148,22 @@ class ShardedCodec:
         self.base = None
         self.total = None
 
-    def compress(self, local_in) -> None:
+    def compress(self, local_in, kernel_events=None) -> None:
         """local_in: this rank's slab (device tensor).  Afterwards: self.header_global (all NHC entries, global
-        offsets), self.body / self.body_len (resident body + local border), self.base (global word offset)."""
+        offsets), self.body / self.body_len (resident body + local border), self.base (global word offset).
+        kernel_events: optional (start, stop) torch.cuda.Event pair recorded tightly around the codec launch."""
         import torch
 
         sh = self.shard
+        if kernel_events:
+            kernel_events[0].record()
         self.compressor.compress_split(local_in, sh.extent, self.header_local, self.body, self.body_len)
+        if kernel_events:
+            kernel_events[1].record()
+        if self.world == 1:
+            # single shard: local offsets are global offsets, nothing to exchange
+            self.header_global = self.header_local[: sh.num_hypercubes]
+            return
         # body words without the local border: the border count is known analytically
         body_only = self.body_len.to(torch.int64) - sh.border
         self.base, self.total, self.lens = exchange_offsets(body_only, self.rank, self.world, self.group)

@@ -237,16 +237,22 @@ EXPORT uint64_t FN(ndzip_oracle_compress)(int dims, const uint32_t *extent, cons
 #ifdef _OPENMP
         const uint32_t slot = HC_SIZE / B * (B + 1);
         /* process in batches so scratch stays bounded (reference: 30 write buffers, cpu_codec.inl:712) */
-        const uint32_t batch = 4096;
-        W *scratch = (W *) malloc((size_t) batch * slot * sizeof(W));
-        uint32_t *len = (uint32_t *) malloc((size_t) batch * sizeof(uint32_t));
-        uint64_t *start = (uint64_t *) malloc((size_t) batch * sizeof(uint64_t));
+        const uint32_t batch = 2048;
+        /* scratch is kept across calls (first-touch page faults of 35-70 MB per call would dominate the timing) */
+        static W *scratch = NULL;
+        static uint32_t *len = NULL;
+        static uint64_t *start = NULL;
+        if (!scratch) {
+            scratch = (W *) malloc((size_t) batch * slot * sizeof(W));
+            len = (uint32_t *) malloc((size_t) batch * sizeof(uint32_t));
+            start = (uint64_t *) malloc((size_t) batch * sizeof(uint64_t));
+        }
         for (uint32_t first = 0; first < g.nhc; first += batch) {
             const uint32_t count = g.nhc - first < batch ? g.nhc - first : batch;
 #pragma omp parallel num_threads(num_threads)
             {
                 W cube[HC_SIZE];
-#pragma omp for schedule(dynamic, 8)
+#pragma omp for schedule(dynamic, 4)
                 for (uint32_t i = 0; i < count; ++i) {
                     FN(load_cube)(data, &g, first + i, cube);
                     FN(ndzip_oracle_forward_transform)(cube, dims);
@@ -263,9 +269,6 @@ EXPORT uint64_t FN(ndzip_oracle_compress)(int dims, const uint32_t *extent, cons
                 memcpy(body + start[i], scratch + (size_t) i * slot, (size_t) len[i] * sizeof(W));
             }
         }
-        free(scratch);
-        free(len);
-        free(start);
 #else
         return 0;
 #endif

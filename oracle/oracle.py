@@ -126,24 +126,31 @@ def border_slices(extent, side: int = 0):
     return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
 
 
-def compress(data: np.ndarray, num_threads: int = 1) -> np.ndarray:
-    """Oracle compress of a C-contiguous float32/float64 array -> stream as uint32/uint64 words."""
+def compress(data: np.ndarray, num_threads: int = 1, out: np.ndarray = None) -> np.ndarray:
+    """Oracle compress of a C-contiguous float32/float64 array -> stream as uint32/uint64 words.
+    `out`: optional preallocated (already touched) buffer of compressed_length_bound words -- timing runs reuse it so
+    first-touch page faults of a fresh buffer are not billed to the codec; the result is then a view into it."""
     data = np.ascontiguousarray(data)
     bits = _bits(data.dtype)
     wdt = np.uint32 if bits == 32 else np.uint64
     extent = data.shape
-    out = np.zeros(max(1, compressed_length_bound(data.dtype, extent)), dtype=wdt)
+    keep = out is not None
+    if out is None:
+        out = np.zeros(max(1, compressed_length_bound(data.dtype, extent)), dtype=wdt)
+    assert out.dtype == wdt and out.size >= max(1, compressed_length_bound(data.dtype, extent))
     fn = getattr(lib(), f"ndzip_oracle_compress_u{bits}")
     n = fn(len(extent), _ext(extent), data.ctypes.data, out.ctypes.data, int(num_threads))
-    return out[: int(n)].copy()
+    return out[: int(n)] if keep else out[: int(n)].copy()
 
 
-def decompress(stream: np.ndarray, dtype, extent, num_threads: int = 1):
-    """Oracle decompress -> (array of `dtype` with shape `extent`, words consumed)."""
+def decompress(stream: np.ndarray, dtype, extent, num_threads: int = 1, out: np.ndarray = None):
+    """Oracle decompress -> (array of `dtype` with shape `extent`, words consumed).  `out`: optional reusable buffer."""
     bits = _bits(dtype)
     stream = np.ascontiguousarray(stream)
     assert _bits(stream.dtype) == bits
-    out = np.zeros(tuple(int(x) for x in extent), dtype=dtype)
+    if out is None:
+        out = np.zeros(tuple(int(x) for x in extent), dtype=dtype)
+    assert out.dtype == np.dtype(dtype) and out.shape == tuple(int(x) for x in extent) and out.flags.c_contiguous
     fn = getattr(lib(), f"ndzip_oracle_decompress_u{bits}")
     n = fn(len(extent), _ext(extent), stream.ctypes.data, out.ctypes.data, int(num_threads))
     return out, int(n)
