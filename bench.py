@@ -74,7 +74,9 @@ def cpu_baseline(host_grid, dims):
     path = os.path.join(shm, f"ndzip_bench_grid_{os.getpid()}.npy")
     np.save(path, host_grid)
     try:
-        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores", OMP_WAIT_POLICY="ACTIVE")
+        # close binding on physical cores was the stable setting on the 2 x 64-core host (tools/cpu_env_probe.sh)
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        env.pop("OMP_WAIT_POLICY", None)
         r = subprocess.run([sys.executable, "-m", "oracle.timing", path, str(cores), "20"], capture_output=True, text=True, cwd=ROOT, env=env,
                            timeout=300)
         t = json.loads(r.stdout.strip().splitlines()[-1])

@@ -237,7 +237,7 @@ EXPORT uint64_t FN(ndzip_oracle_compress)(int dims, const uint32_t *extent, cons
 #ifdef _OPENMP
         const uint32_t slot = HC_SIZE / B * (B + 1);
         /* process in batches so scratch stays bounded (reference: 30 write buffers, cpu_codec.inl:712) */
-        const uint32_t batch = 2048;
+        const uint32_t batch = 4096;
         /* scratch is kept across calls (first-touch page faults of 35-70 MB per call would dominate the timing) */
         static W *scratch = NULL;
         static uint32_t *len = NULL;
@@ -247,28 +247,33 @@ EXPORT uint64_t FN(ndzip_oracle_compress)(int dims, const uint32_t *extent, cons
             len = (uint32_t *) malloc((size_t) batch * sizeof(uint32_t));
             start = (uint64_t *) malloc((size_t) batch * sizeof(uint64_t));
         }
-        for (uint32_t first = 0; first < g.nhc; first += batch) {
-            const uint32_t count = g.nhc - first < batch ? g.nhc - first : batch;
+        /* ONE parallel region for the whole call (a region per batch means waking the team dozens of times) */
+        uint64_t running = 0;
 #pragma omp parallel num_threads(num_threads)
-            {
-                W cube[HC_SIZE];
+        {
+            W cube[HC_SIZE];
+            for (uint32_t first = 0; first < g.nhc; first += batch) {
+                const uint32_t count = g.nhc - first < batch ? g.nhc - first : batch;
 #pragma omp for schedule(dynamic, 4)
                 for (uint32_t i = 0; i < count; ++i) {
                     FN(load_cube)(data, &g, first + i, cube);
                     FN(ndzip_oracle_forward_transform)(cube, dims);
                     len[i] = FN(ndzip_oracle_encode_cube)(cube, scratch + (size_t) i * slot);
                 }
-            }
-            for (uint32_t i = 0; i < count; ++i) {
-                start[i] = offset;
-                offset += len[i];
-                header[first + i] = (uint32_t) offset;
-            }
-#pragma omp parallel for schedule(static) num_threads(num_threads)
-            for (uint32_t i = 0; i < count; ++i) {
-                memcpy(body + start[i], scratch + (size_t) i * slot, (size_t) len[i] * sizeof(W));
+                /* in-order stream assembly: the serial dependency the reference resolves with its write queue */
+#pragma omp single
+                for (uint32_t i = 0; i < count; ++i) {
+                    start[i] = running;
+                    running += len[i];
+                    header[first + i] = (uint32_t) running;
+                }
+#pragma omp for schedule(static)
+                for (uint32_t i = 0; i < count; ++i) {
+                    memcpy(body + start[i], scratch + (size_t) i * slot, (size_t) len[i] * sizeof(W));
+                }
             }
         }
+        offset = running;
 #else
         return 0;
 #endif
