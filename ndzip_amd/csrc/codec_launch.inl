@@ -354,46 +354,48 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
 #endif
 }
 
-// ---- double-buffered variant (f32) ----------------------------------------------------------------------------------
-// The encoded runs of a tile go to a second LDS region Y, so a tile is written out ONE ITERATION LATER:
-//   * its look-back window is read asynchronously at the top of the next iteration and consumed after that
-//     iteration's stencil + transposes -- an in-launch hand-off on this part costs about the time the reading CU's own
-//     memory queue takes to drain (several microseconds under a streaming load), which is now hidden, and the
-//     predecessors have had a whole iteration to publish;
+// ---- deferred write-out variant (f32) --------------------------------------------------------------------------------
+// A tile is written out ONE ITERATION after it was encoded:
+//   * its look-back window is read asynchronously at the top of the next iteration (before that wavefront's prefetch
+//     loads: vector loads return in order) and consumed after that iteration's stencil -- an in-launch hand-off on
+//     this part costs about as long as the reading CU's memory queue takes to drain (several microseconds under a
+//     streaming load), which is now hidden, and the predecessors have had a whole iteration to publish;
 //   * the next tile's input is prefetched a whole iteration ahead, so HBM stays busy during compute.
-// Price: X + Y = 70.6 KiB of LDS per workgroup -> 2 workgroups (8 wavefronts) per CU, each of them rarely stalled.
+// The encoded tile waits in REGISTERS (its 32 transposed planes per work-item), not in a second LDS buffer: the LDS
+// footprint stays at one staging region per hypercube (37 KiB per workgroup) and the register budget of 168 still
+// admits 3 workgroups = 12 wavefronts per CU (a second LDS buffer allowed only 2; measured 0.27 vs 0.32 ms).
 template<typename T, int Dims>
 struct db_cfg {
     using C = tile_cfg<T, Dims>;
-    using W = typename C::W;
-    using L = typename C::L;
-    static constexpr uint32_t x_bytes = C::K * L::cube_bytes;
-    static constexpr uint32_t y_bytes = C::K * profile<T, Dims>::max_hc_words * sizeof(W);
-    static constexpr uint32_t smem_bytes = x_bytes + y_bytes + L::zero_bytes + 64;
+    static constexpr uint32_t smem_bytes = C::smem_bytes;
+#ifdef NDZIP_EXP_DB_WAVES
+    static constexpr int min_waves_per_simd = NDZIP_EXP_DB_WAVES;
+#else
+    static constexpr int min_waves_per_simd = 3;
+#endif
 };
 
 template<typename T, int Dims, bool Aligned>
-__global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), 2)
+__global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (db_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
         typename word_of<T>::type *__restrict__ body, tile_desc *desc, uint32_t *tickets, const uint32_t num_classes,
         uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags) {
     using C = tile_cfg<T, Dims>;
-    using D = db_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
     using P = profile<T, Dims>;
+    static_assert(P::B == 32, "register-buffered variant is for 32-bit words");
     constexpr int K = C::K;
     constexpr int NW = C::threads / 64;
-    constexpr uint32_t w32 = sizeof(W) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x);
     const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
     const int lane = tid & 63, wave = tid >> 6;
-    char *cube = smem + grp * L::cube_bytes;                                   // X: staging of this group's hypercube
-    uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem + D::x_bytes);     // Y: the K encoded runs, back to back
-    char *zero = smem + D::x_bytes + D::y_bytes;
-    uint32_t *misc = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);      // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
+    char *cube = smem + grp * L::cube_bytes;                              // staging of this group's hypercube
+    uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);             // later: the K encoded runs, back to back
+    char *zero = smem + K * L::cube_bytes;
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero)[i] = 0;
     stagger_start(exp_flags >> 8);
@@ -401,14 +403,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls;
-#ifdef NDZIP_EXP_STATIC
-    uint32_t tile = blockIdx.x;
-    (void) ticket_counter;
-#else
     if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
     uint32_t tile = misc[NW + 1] * num_classes + cls;
-#endif
 
 #ifdef NDZIP_EXP_PHASE_TIMING
     const bool timing = (exp_flags & 16u) != 0;
@@ -429,55 +426,55 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (first_hc >= gg.nhc) first_hc = gg.nhc - 1;
         load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, first_hc), t, pre);
     }
-    // the previous tile: encoded in Y, aggregate published, waiting for its prefix
-    bool have_prev = false;
-    uint32_t prev_tile = 0, prev_aggregate = 0, prev_end = 0;  // prev_end: end of this group's run within the tile
-    bool prev_active = false;
-    uint32_t prev_hc = 0;
+    // the previous tile: transposed planes in registers, aggregate published, waiting for its prefix
+    bool have_prev = false, prev_active = false;
+    uint32_t prev_tile = 0, prev_aggregate = 0, prev_run_start = 0, prev_my_len = 0, prev_chunk_excl = 0, prev_hc = 0;
+    uint32_t prev_head = 0;
+    uint32_t planes[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) planes[j] = 0;
     for (;;) {
         const bool have_cur = tile < ntiles;
         if (!have_cur && !have_prev) break;
         const uint32_t hc = tile * K + grp;
         const bool active = have_cur && hc < gg.nhc;
         if (have_cur) {
-#ifdef NDZIP_EXP_STATIC
-            if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
-#else
             uint32_t next_ticket = 0;
             if (tid == 0) next_ticket = atomicAdd(ticket_counter, 1u);
             if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
             if (tid == 0) misc[NW + 1] = next_ticket;
-#endif
         }
         NDZIP_PHASE(0)  // ticket + wait prefetch + stage
-        __syncthreads();  // B1: X staged, next ticket known
-#ifdef NDZIP_EXP_STATIC
-        const uint32_t next_tile = have_cur ? tile + gridDim.x : tile;
-#else
+        __syncthreads();  // B1: cube staged, next ticket known
         const uint32_t next_tile = have_cur ? misc[NW + 1] * num_classes + cls : tile;
-#endif
         tile_desc window = 0;
         __builtin_amdgcn_sched_barrier(0);
         if (have_prev && wave == 0) window = lookback_issue(desc, prev_tile, lane);
         __builtin_amdgcn_sched_barrier(0);
-        encoded_chunk<P::B> c;
-        uint32_t incl = 0;
+        W r[vals_per_thread];
+        uint32_t head = 0, count = 0, incl = 0;
         if (have_cur) {
+            NDZIP_PHASE(1)  // B1 + window issue
+            stencil_residuals<T, Dims>(cube, zero, t, r);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) head |= r[j];
+            count = active ? static_cast<uint32_t>(__builtin_popcount(head)) : 0u;
+            incl = wave_inclusive_scan(count, lane);
+            if (lane == 63) misc[wave] = incl;
+        }
+        NDZIP_PHASE(2)  // stencil + head + chunk scan
+        __syncthreads();  // B2: all stencil reads done (staging region reusable), wave totals known
+        {
+            // prefetch of the next tile: issued after the stencil so its 32 registers are not live across it (the
+            // previous tile's planes are); the loads fly during resolve, copy-out and the transposes.  Unconditional
+            // (clamped) on purpose: a conditional load keeps the old registers live around the whole loop.
+            __builtin_amdgcn_sched_barrier(0);
             uint32_t next_hc = next_tile * K + grp;
             if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
             load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
             __builtin_amdgcn_sched_barrier(0);
-            NDZIP_PHASE(1)  // B1 + window issue + prefetch issue
-            W r[vals_per_thread];
-            stencil_residuals<T, Dims>(cube, zero, t, r);
-            NDZIP_PHASE(2)  // stencil
-            encode_chunk<T, Dims>(r, t, c);
-            incl = wave_inclusive_scan(active ? c.scan_in : 0u, lane);
-            if (lane == 63) misc[wave] = incl;
         }
-        NDZIP_PHASE(3)  // transposes + scan
-        __syncthreads();  // B2: wave totals known
-        uint32_t run_start = 0, aggregate = 0, my_len = 0;
+        uint32_t run_start = 0, aggregate = 0, my_len = 0, chunk_excl = 0;
         if (have_cur) {
 #pragma unroll
             for (int g = 0; g < K; ++g) {
@@ -486,38 +483,53 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
                 if (g == grp) my_len = len_g;
                 aggregate += len_g;
             }
-            if (tid == 0) publish_aggregate(desc, tile, aggregate);
+            chunk_excl = ((wave & 1) ? misc[2 * grp] : 0u) + incl - count;
+            if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
-        if (have_prev && wave == 0) {
-            const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
-                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
-            if (tid == 0) misc[NW] = exclusive;
-        }
-        NDZIP_PHASE(4)  // B2 + publish + resolve (wave 0)
-        __syncthreads();  // B3: prefix of the previous tile known
         if (have_prev) {
-            const uint32_t prefix = misc[NW];
-            if (!(exp_flags & 2u)) {
-                copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
-            }
-            if (prev_active && t == 0) {
-                header[prev_hc] = prefix + prev_end;  // offset_after(hc), common.hh:342-347
-                if (prev_hc == gg.nhc - 1) {
-                    if (out_len) *out_len = len_extra + prefix + prev_end;
-                    if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
+            // the previous tile's planes leave the registers: compact them into the (now free) staging region
+            if (prev_active && !(exp_flags & 4u)) {
+                uint32_t *run = tile_run + prev_run_start;
+                uint32_t pos = P::head_words + prev_chunk_excl;
+                run[t] = prev_head;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    if (planes[i] != 0) run[pos++] = planes[i];
                 }
             }
+            if (wave == 0) {
+                const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
+                                                            : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
+                if (tid == 0) misc[NW] = exclusive;
+            }
         }
-        NDZIP_PHASE(5)  // B3 + copy-out
-        __syncthreads();  // B4: Y has been read, the current tile's runs may replace it
-        if (active && !(exp_flags & 4u)) {
-            write_chunk<T, Dims>(c, tile_run + run_start * w32, ((wave & 1) ? misc[2 * grp] : 0u) + incl - c.count, t);
+        NDZIP_PHASE(3)  // B2 + publish + plane writes (prev) + resolve (prev)
+        __syncthreads();  // B3: previous tile's runs complete in LDS, its prefix known
+        if (have_prev) {
+            const uint32_t prefix = misc[NW];
+            if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
+            if (prev_active && t == 0) {
+                header[prev_hc] = prefix + prev_run_start + prev_my_len;  // offset_after(hc), common.hh:342-347
+                if (prev_hc == gg.nhc - 1 && out_len) *out_len = len_extra + prefix + prev_run_start + prev_my_len;
+            }
         }
-        NDZIP_PHASE(6)  // B4 + plane writes
+        NDZIP_PHASE(4)  // B3 + copy-out (prev)
+        // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
+        if (have_cur) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) planes[j] = r[j];
+            transpose32(planes);
+        }
+        NDZIP_PHASE(5)  // transposes
+        __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them
+        NDZIP_PHASE(6)
         have_prev = have_cur;
         prev_tile = tile;
         prev_aggregate = aggregate;
-        prev_end = run_start + my_len;
+        prev_run_start = run_start;
+        prev_my_len = my_len;
+        prev_chunk_excl = chunk_excl;
+        prev_head = head;
         prev_active = active;
         prev_hc = hc;
         tile = next_tile;
@@ -653,9 +665,17 @@ hipError_t launch_compress_profile(const compress_args &a) {
     using W = typename C::W;
     const uint32_t ntiles = (a.gg.nhc + C::K - 1) / C::K;
     if (ntiles == 0) return hipSuccess;
-    constexpr bool use_db = sizeof(T) == 4;  // double-buffered variant where X + Y still leaves 2 workgroups per CU
-    auto kernel = use_db ? compress_kernel_db<T, Dims, Aligned> : compress_kernel<T, Dims, Aligned>;
-    constexpr uint32_t smem_bytes = use_db ? db_cfg<T, Dims>::smem_bytes : C::smem_bytes;
+    // f32: deferred write-out with the encoded tile held in registers; f64 (twice the registers per plane set): the
+    // single-buffered kernel
+    constexpr bool use_db = sizeof(T) == 4;
+    constexpr uint32_t smem_bytes = C::smem_bytes;
+    void (*kernel)(const W *, const grid_geom, uint32_t *, W *, tile_desc *, uint32_t *, const uint32_t, uint32_t *, uint32_t, uint32_t *,
+            const uint32_t);
+    if constexpr (use_db) {
+        kernel = compress_kernel_db<T, Dims, Aligned>;
+    } else {
+        kernel = compress_kernel<T, Dims, Aligned>;
+    }
     // persistent grid, fully resident: bounded by the occupancy query and by what the LDS alone admits
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {

@@ -165,7 +165,7 @@ class ShardedCodec:
             self.header_global = self.header_local[: sh.num_hypercubes]
             return
         # body words without the local border: the border count is known analytically
-        body_only = self.body_len.to(torch.int64) - sh.border
+        body_only = (self.body_len.to(torch.int64) & 0xFFFFFFFF) - sh.border  # the length word is a uint32
         self.base, self.total, self.lens = exchange_offsets(body_only, self.rank, self.world, self.group)
         self.base32.copy_(wrap_u32_to_i32(self.base))
         self.compressor.offset_header_device(self.header_local, sh.num_hypercubes, self.base32)
