@@ -232,6 +232,26 @@ NDZIP_DEV uint64_t local_offset(const grid_geom &gg, uint32_t k) {
 // wave / group scans
 // ---------------------------------------------------------------------------------------------------------
 
+// Value of lane (l - D) for the lanes of an 8-lane group (l % 8 >= D), 0 for the others, as a DPP row shift instead of
+// ds_bpermute + select: row_shr:D moves within 16-lane rows (bound_ctrl zero-fills at the row start); the lanes of the
+// second group of a row that would read across the group boundary are cleared with `keep` (all ones iff l % 8 >= D) or,
+// for D == 4, by the bank mask alone.
+template<int D>
+NDZIP_DEV uint32_t group8_shift_up(uint32_t v, uint32_t keep) {
+    static_assert(D == 1 || D == 2 || D == 4);
+    if constexpr (D == 4) {
+        return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x110 + D, 0xf, 0xa, false));
+    } else {
+        return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x110 + D, 0xf, 0xf, true)) & keep;
+    }
+}
+template<int D>
+NDZIP_DEV uint64_t group8_shift_up(uint64_t v, uint32_t keep) {
+    const uint32_t lo = group8_shift_up<D>(static_cast<uint32_t>(v), keep);
+    const uint32_t hi = group8_shift_up<D>(static_cast<uint32_t>(v >> 32), keep);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
 NDZIP_DEV uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -545,8 +565,11 @@ NDZIP_DEV uint32_t encode_hypercube(const typename profile<T, Dims>::word *__res
 //   out     global array (as words), origin = element offset of the hypercube
 // ---------------------------------------------------------------------------------------------------------
 
-// phase 1 of decode: encoded run at cube[0 .. L) -> residuals r[32] of work-item t
-template<typename T, int Dims>
+// phase 1 of decode: encoded run at cube[0 .. L) -> residuals r[32] of work-item t.
+// ComplementInPlaneDomain: also undo complement_negative, but BEFORE the inverse transpose: flipping the low B-1 bits of
+// every negative value is "XOR every plane below the sign plane with the sign plane" -- B-1 operations on plane words
+// instead of 3 per value (ashr, lshr, xor) afterwards.
+template<typename T, int Dims, bool ComplementInPlaneDomain = false>
 NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typename profile<T, Dims>::word (&r)[vals_per_thread]) {
     using P = profile<T, Dims>;
     constexpr int B = P::B;
@@ -567,6 +590,10 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
             const uint32_t above = i == 0 ? 0u : (head & ~(0xffffffffu >> i));
             const uint32_t w = in32[base + static_cast<uint32_t>(__builtin_popcount(above))];
             r[i] = ((head >> (31 - i)) & 1u) ? w : 0u;
+        }
+        if constexpr (ComplementInPlaneDomain) {
+#pragma unroll
+            for (int i = 1; i < 32; ++i) r[i] ^= r[0];
         }
         transpose32(r);
     } else {
@@ -593,6 +620,13 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
             const uint32_t w = in32[2 * (base + n_hi + static_cast<uint32_t>(__builtin_popcount(above))) + half];
             lo[i] = ((head_lo >> (31 - i)) & 1u) ? w : 0u;
         }
+        if constexpr (ComplementInPlaneDomain) {
+            // hi[0] is this lane's half of the sign plane; it covers the same 32 values as all its other plane halves
+#pragma unroll
+            for (int i = 1; i < 32; ++i) hi[i] ^= hi[0];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) lo[i] ^= hi[0];
+        }
         transpose32(hi);
         transpose32(lo);
 #pragma unroll
@@ -600,8 +634,9 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
     }
 }
 
-// phases 2+3 of decode: residuals -> complement_negative -> prefix sums along every axis -> rotr1 -> global
-template<typename T, int Dims, bool Aligned>
+// phases 2+3 of decode: residuals -> complement_negative (unless already done) -> prefix sums along every axis ->
+// rotr1 -> global
+template<typename T, int Dims, bool Aligned, bool AlreadyComplemented = false>
 NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[vals_per_thread],
         typename profile<T, Dims>::word *__restrict__ out, const grid_geom &gg, uint64_t origin, bool active, char *cube,
         uint32_t *xchg, int t) {
@@ -609,8 +644,10 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
     using W = typename P::word;
     using L = lds_layout<W>;
     const int lane = t & 63, wave = t >> 6;
+    if constexpr (!AlreadyComplemented) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) r[j] = complement_negative(r[j]);
+        for (int j = 0; j < 32; ++j) r[j] = complement_negative(r[j]);
+    }
 
     // ---- phase 2: prefix sums that stay inside the work-item / wavefront ----------------------------------
     if constexpr (Dims == 1) {
@@ -642,21 +679,17 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
 #pragma unroll
         for (int j = 0; j < 16; ++j) r[16 + j] += r[j];
         const int yp = t & 7;
+        const uint32_t keep1 = yp >= 1 ? ~0u : 0u, keep2 = yp >= 2 ? ~0u : 0u;
 #pragma unroll
-        for (int d = 1; d < 8; d <<= 1) {
+        for (int j = 0; j < 16; ++j) r[16 + j] += group8_shift_up<1>(r[16 + j], keep1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const W o = __shfl_up(r[16 + j], d, 8);
-                if (yp >= d) r[16 + j] += o;
-            }
-        }
+        for (int j = 0; j < 16; ++j) r[16 + j] += group8_shift_up<2>(r[16 + j], keep2);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const W o = __shfl_up(r[16 + j], 1, 8);
-            // rows of this lane: first row gets the inclusive total of the previous lane; the second row
-            // already holds the inclusive total of this lane
-            if (yp > 0) r[j] += o;
-        }
+        for (int j = 0; j < 16; ++j) r[16 + j] += group8_shift_up<4>(r[16 + j], 0u);
+        // rows of this lane: the first row gets the inclusive total of the previous lane; the second row already
+        // holds the inclusive total of this lane
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r[j] += group8_shift_up<1>(r[16 + j], keep1);
     }
 
     __syncthreads();  // every work-item has consumed the encoded run: overwrite `cube` with values
@@ -761,8 +794,8 @@ NDZIP_DEV void decode_hypercube(typename profile<T, Dims>::word *__restrict__ ou
         bool active, char *cube, const char *run, uint32_t *xchg, int t) {
     // `run`: first word of the encoded run inside `cube` (4-byte aligned; consumed before `cube` is overwritten)
     typename profile<T, Dims>::word r[vals_per_thread];
-    decode_residuals<T, Dims>(run, xchg, t, r);
-    inverse_transform_hypercube<T, Dims, Aligned>(r, out, gg, origin, active, cube, xchg, t);
+    decode_residuals<T, Dims, true>(run, xchg, t, r);
+    inverse_transform_hypercube<T, Dims, Aligned, true>(r, out, gg, origin, active, cube, xchg, t);
 }
 
 }  // namespace ndzip_hip
