@@ -293,22 +293,29 @@ struct input_regs {
 };
 
 // phase 0a: issue the coalesced global loads of hypercube `origin` (nothing waits here)
-template<typename T, int Dims, bool Aligned>
+// Part 0 = the first `Split` vectors (values) of the work-item, part 1 = the rest, part -1 = everything: the deferred
+// write-out kernel issues part 0 before the stencil (a full iteration ahead) and part 1 after it, which caps the
+// registers that are live across the stencil.
+template<typename T, int Dims, bool Aligned, int Part = -1, int Split = 0>
 NDZIP_DEV void load_hypercube_regs(const typename profile<T, Dims>::word *__restrict__ in, const grid_geom &gg,
         uint64_t origin, int t, input_regs<typename profile<T, Dims>::word, Aligned> &regs) {
     using W = typename profile<T, Dims>::word;
     using R = input_regs<W, Aligned>;
+    constexpr int n = Aligned ? R::NV : vals_per_thread;
+    constexpr int split = Aligned ? Split : Split * (vals_per_thread / R::NV);
+    constexpr int first = Part == 1 ? split : 0;
+    constexpr int last = Part == 0 ? split : n;
     // vector i of work-item t covers cube-local values k_i = (i*128 + t) * VE; 128*VE values are a whole number of
     // rows / planes, so the global offset is affine in i: one per-lane base plus a uniform step.
     if constexpr (Aligned) {
         const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
         const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE);
 #pragma unroll
-        for (int i = 0; i < R::NV; ++i) regs.v[i] = *reinterpret_cast<const vec16 *>(base + i * step);
+        for (int i = first; i < last; ++i) regs.v[i] = *reinterpret_cast<const vec16 *>(base + i * step);
     } else {
         // scalar path for unaligned extents: 128 values are half a 3D plane, so the offset is NOT affine in i
 #pragma unroll
-        for (int i = 0; i < vals_per_thread; ++i) {
+        for (int i = first; i < last; ++i) {
             regs.s[i] = in[origin + local_offset<Dims>(gg, static_cast<uint32_t>(i * threads_per_hc + t))];
         }
     }

@@ -385,6 +385,11 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     using L = typename C::L;
     using P = profile<T, Dims>;
     static_assert(P::B == 32, "register-buffered variant is for 32-bit words");
+#ifdef NDZIP_EXP_EARLY_VECTORS
+    constexpr int early_vectors = NDZIP_EXP_EARLY_VECTORS;
+#else
+    constexpr int early_vectors = 2;  // of 8; measured on 512^3: 0 -> 0.258 ms, 2 -> 0.245, 4 -> 0.254, 8 (spills) -> 0.34
+#endif
     constexpr int K = C::K;
     constexpr int NW = C::threads / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -451,6 +456,12 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         __builtin_amdgcn_sched_barrier(0);
         if (have_prev && wave == 0) window = lookback_issue(desc, prev_tile, lane);
         __builtin_amdgcn_sched_barrier(0);
+        uint32_t next_hc = next_tile * K + grp;
+        if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
+        const uint64_t next_origin = hc_origin<Dims>(gg, next_hc);
+        // early part of the next tile's prefetch (a whole iteration ahead of its use)
+        load_hypercube_regs<T, Dims, Aligned, 0, early_vectors>(in, gg, next_origin, t, pre);
+        __builtin_amdgcn_sched_barrier(0);
         W r[vals_per_thread];
         uint32_t head = 0, count = 0, incl = 0;
         if (have_cur) {
@@ -464,16 +475,12 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         }
         NDZIP_PHASE(2)  // stencil + head + chunk scan
         __syncthreads();  // B2: all stencil reads done (staging region reusable), wave totals known
-        {
-            // prefetch of the next tile: issued after the stencil so its 32 registers are not live across it (the
-            // previous tile's planes are); the loads fly during resolve, copy-out and the transposes.  Unconditional
-            // (clamped) on purpose: a conditional load keeps the old registers live around the whole loop.
-            __builtin_amdgcn_sched_barrier(0);
-            uint32_t next_hc = next_tile * K + grp;
-            if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
-            load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
+        // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
+        // live around the whole loop.
+        __builtin_amdgcn_sched_barrier(0);
+        load_hypercube_regs<T, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
+        __builtin_amdgcn_sched_barrier(0);
         uint32_t run_start = 0, aggregate = 0, my_len = 0, chunk_excl = 0;
         if (have_cur) {
 #pragma unroll
