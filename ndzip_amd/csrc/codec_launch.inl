@@ -95,24 +95,43 @@ NDZIP_DEV void stagger_start(uint32_t iteration_kcycles) {
 
 // first look-back window of `tile`, issued early so its latency hides behind other work (vector loads return in
 // order: issue this BEFORE any bulk load of the same wavefront)
-NDZIP_DEV tile_desc lookback_issue(const tile_desc *desc, uint32_t tile, int lane) {
-    const long long idx = static_cast<long long>(tile) - 1 - lane;
-    if (lane >= lookback_lanes) return st_skip;
-    return idx >= 0 ? desc_load(desc + idx) : st_inclusive;
+#ifndef NDZIP_LOOKBACK_PREFETCH
+#define NDZIP_LOOKBACK_PREFETCH 1
+#endif
+constexpr int lookback_prefetch = NDZIP_LOOKBACK_PREFETCH;  // windows read ahead of time (asynchronously)
+
+struct lookback_windows {
+    tile_desc d[lookback_prefetch];
+};
+
+NDZIP_DEV void lookback_issue(const tile_desc *desc, uint32_t tile, int lane, lookback_windows &w) {
+#pragma unroll
+    for (int j = 0; j < lookback_prefetch; ++j) {
+        const long long idx = static_cast<long long>(tile) - 1 - lane - j * lookback_lanes;
+        w.d[j] = lane >= lookback_lanes ? st_skip : idx >= 0 ? desc_load(desc + idx) : st_inclusive;
+    }
 }
 
 template<bool Preloaded>
 NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane,
-        tile_desc d) {
+        const lookback_windows &pre, uint32_t *hop_count = nullptr, uint32_t *poll_count = nullptr) {
     if (tile == 0) return 0;
     uint32_t exclusive = 0;
     long long base = static_cast<long long>(tile) - 1;
     bool timed_out = false;
     uint32_t spins = 0;
-    bool use_preloaded = Preloaded;
+    int hop = 0;
     for (;;) {
         bool found = false;
         int lf = 0;
+        bool use_preloaded = Preloaded && hop < lookback_prefetch;
+        tile_desc d = 0;
+        if (use_preloaded) {
+#pragma unroll
+            for (int j = 0; j < lookback_prefetch; ++j) {
+                if (j == hop) d = pre.d[j];
+            }
+        }
         for (;;) {
             if (!use_preloaded) {
                 const long long idx = base - lane;
@@ -132,6 +151,7 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile,
                 wait_pos = __builtin_ctzll(invalid);
             }
             if (wait_pos < 0) break;
+            if (poll_count) ++*poll_count;
             // the nearest missing predecessor: one lane polls it, then the window is read again
             if (lane == 0) {
                 const tile_desc *p = desc + (base - wait_pos);
@@ -150,7 +170,9 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile,
         const bool take = !found || lane <= lf;
         exclusive += wave_sum(take ? static_cast<uint32_t>(d) : 0u);
         if (found || timed_out) break;
+        if (hop_count) ++*hop_count;
         base -= lookback_lanes;
+        ++hop;
     }
     if (timed_out && lane == 0) atomicOr(err, 1u);
     if (lane == 0) desc_store(desc + tile, st_inclusive | (exclusive + aggregate));
@@ -158,7 +180,8 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile,
 }
 
 NDZIP_DEV uint32_t resolve_exclusive_prefix(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane) {
-    return resolve_exclusive_prefix_impl<false>(desc, tile, aggregate, err, lane, 0ull);
+    lookback_windows none{};
+    return resolve_exclusive_prefix_impl<false>(desc, tile, aggregate, err, lane, none);
 }
 
 // Coalesced copy of `n` words from LDS (16-byte aligned `src`) to global: scalar head up to the first 16-byte
@@ -452,9 +475,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         NDZIP_PHASE(0)  // ticket + wait prefetch + stage
         __syncthreads();  // B1: cube staged, next ticket known
         const uint32_t next_tile = have_cur ? misc[NW + 1] * num_classes + cls : tile;
-        tile_desc window = 0;
+        lookback_windows window{};
         __builtin_amdgcn_sched_barrier(0);
-        if (have_prev && wave == 0) window = lookback_issue(desc, prev_tile, lane);
+        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t next_hc = next_tile * K + grp;
         if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
@@ -506,7 +529,11 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             }
             if (wave == 0) {
                 const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
+#ifdef NDZIP_EXP_PHASE_TIMING
+                                                            : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window, &ticks[6], &ticks[7]);
+#else
                                                             : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
+#endif
                 if (tid == 0) misc[NW] = exclusive;
             }
         }
@@ -527,9 +554,8 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             for (int j = 0; j < 32; ++j) planes[j] = r[j];
             transpose32(planes);
         }
-        NDZIP_PHASE(5)  // transposes
+        NDZIP_PHASE(5)  // transposes (+ B4 wait next)
         __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them
-        NDZIP_PHASE(6)
         have_prev = have_cur;
         prev_tile = tile;
         prev_aggregate = aggregate;

@@ -1,0 +1,62 @@
+"""The compress kernel hands tile lengths between workgroups inside one launch (decoupled look-back).  The MI355X guide's
+rule for such hand-offs: test under UNEVEN load, checking every word.  Here the codec runs many times while other
+streams keep the GPU busy with unrelated kernels (so workgroups start late, get descheduled behind other work and
+finish out of order), on data whose hypercubes have very different encoded lengths (uneven per-tile work)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.util import random_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _uneven_grid(shape, dtype, seed):
+    """zeros, smooth ramps and raw random bits mixed per slab: encoded tile lengths from the minimum to the maximum"""
+    rng = np.random.default_rng(seed)
+    a = np.zeros(shape, dtype)
+    n0 = shape[0]
+    a[n0 // 4: n0 // 2] = (np.arange(a[n0 // 4: n0 // 2].size).reshape(a[n0 // 4: n0 // 2].shape) % 977).astype(dtype) * dtype(0.125)
+    a[n0 // 2: 3 * n0 // 4] = random_bits(a[n0 // 2: 3 * n0 // 4].shape, dtype, seed)
+    a[3 * n0 // 4:] = rng.random(a[3 * n0 // 4:].shape).astype(dtype)
+    return a
+
+
+@pytest.mark.parametrize("dtype,shape", [(np.float32, (192, 256, 256)), (np.float64, (2048, 1536)), (np.float32, (4096 * 700,))])
+def test_compress_under_background_load(hiplib, cuda_device, dtype, shape):
+    import torch
+
+    import ndzip_amd
+
+    data = _uneven_grid(shape, dtype, 3)
+    want = oracle.compress(data, num_threads=oracle.max_threads())
+    wdt = torch.int32 if dtype == np.float32 else torch.int64
+    d_in = torch.from_numpy(data).to(cuda_device)
+    main = torch.cuda.Stream(device=cuda_device)
+    noise = [torch.cuda.Stream(device=cuda_device) for _ in range(2)]
+    big = torch.empty(64 << 20, dtype=torch.float32, device=cuda_device)
+    m = torch.randn(2048, 2048, device=cuda_device)
+    with torch.cuda.stream(main):
+        comp = ndzip_amd.make_hip_compressor(dtype, ndzip_amd.CompressorRequirements(shape), main.cuda_stream)
+        d_out = [torch.zeros(ndzip_amd.compressed_length_bound(dtype, shape), dtype=wdt, device=cuda_device) for _ in range(2)]
+        d_len = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    torch.cuda.synchronize()
+    for it in range(12):
+        # unrelated work of varying size on other streams: occupies CUs and memory channels while the codec runs
+        with torch.cuda.stream(noise[0]):
+            for _ in range(1 + it % 3):
+                big.mul_(1.0001)
+        with torch.cuda.stream(noise[1]):
+            for _ in range(1 + (it * 7) % 4):
+                m = (m @ m).clamp_(-1, 1)
+        with torch.cuda.stream(main):
+            out = d_out[it % 2]
+            comp.compress(d_in, shape, out, d_len)
+        if it % 4 == 3:
+            torch.cuda.synchronize()
+            comp.check()
+            n = int(d_len.cpu().numpy().view(np.uint32)[0])
+            got = out[:n].cpu().numpy().view(want.dtype)
+            assert n == len(want) and np.array_equal(got, want), f"iteration {it}"
+    torch.cuda.synchronize()
+    comp.check()
