@@ -241,6 +241,27 @@ EXPORT uint32_t ndzip_oracle_border_slices(int dims, const uint32_t *extent, uin
     return n;
 }
 
+/* First-touch helper for timing runs on multi-socket hosts: copies (src != NULL) or zero-fills `bytes` at `dst` in
+ * 2 MiB blocks spread over the OpenMP team, so the pages end up distributed over the NUMA nodes instead of all on the
+ * node of the Python main thread. */
+EXPORT void ndzip_oracle_parallel_copy(void *dst, const void *src, uint64_t bytes, int num_threads) {
+    const uint64_t block = 2u << 20;
+    const uint64_t nblocks = (bytes + block - 1) / block;
+    (void) num_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(num_threads > 1 ? num_threads : 1)
+#endif
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        const uint64_t off = b * block;
+        const uint64_t n = bytes - off < block ? bytes - off : block;
+        if (src) {
+            memcpy((char *) dst + off, (const char *) src + off, n);
+        } else {
+            memset((char *) dst + off, 0, n);
+        }
+    }
+}
+
 EXPORT int ndzip_oracle_max_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);

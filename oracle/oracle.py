@@ -207,6 +207,17 @@ def load_cube(data: np.ndarray, hc: int) -> np.ndarray:
     return out
 
 
+def parallel_empty_like(a: np.ndarray, num_threads: int, copy: bool = True) -> np.ndarray:
+    """A new array whose pages are first-touched by the OpenMP team (copy of `a`, or zeros) -- timing runs only."""
+    a = np.ascontiguousarray(a)
+    out = np.empty_like(a)
+    L = lib()
+    L.ndzip_oracle_parallel_copy.restype = None
+    L.ndzip_oracle_parallel_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+    L.ndzip_oracle_parallel_copy(out.ctypes.data, a.ctypes.data if copy else None, a.nbytes, int(num_threads))
+    return out
+
+
 def max_threads() -> int:
     return int(lib().ndzip_oracle_max_threads())
 

@@ -17,8 +17,10 @@ def main():
 
     grid = np.load(path, mmap_mode=None)
     wdt = np.uint32 if grid.dtype.itemsize == 4 else np.uint64
-    sbuf = np.zeros(oracle.compressed_length_bound(grid.dtype, grid.shape), dtype=wdt)
-    obuf = np.zeros(grid.shape, dtype=grid.dtype)
+    # spread the pages of all three buffers over the NUMA nodes (first touch by the OpenMP team)
+    grid = oracle.parallel_empty_like(grid, threads, copy=True)
+    sbuf = oracle.parallel_empty_like(np.empty(oracle.compressed_length_bound(grid.dtype, grid.shape), dtype=wdt), threads, copy=False)
+    obuf = oracle.parallel_empty_like(np.empty(grid.shape, dtype=grid.dtype), threads, copy=False)
     stream = oracle.compress(grid, threads, out=sbuf)  # untimed: touches buffers, starts the thread team
     oracle.decompress(stream, grid.dtype, grid.shape, threads, out=obuf)
     tc, td = [], []
