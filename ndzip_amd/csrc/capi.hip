@@ -224,7 +224,7 @@ int ndzip_hip_compressor_create(int dtype, int dims, uint32_t max_num_hypercubes
     auto *c = new ndzip_hip_compressor{dtype, dims, max_num_hypercubes, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, cus};
     const uint32_t tiles = dtype == NDZIP_HIP_F32 ? compress_num_tiles<float>(dims, max_num_hypercubes)
                                                   : compress_num_tiles<double>(dims, max_num_hypercubes);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->desc), (static_cast<size_t>(tiles) + 32) * sizeof(tile_desc));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->desc), (static_cast<size_t>(tiles) + scratch_extra_descs) * sizeof(tile_desc));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->err), sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(c->err, 0, sizeof(uint32_t), c->stream);
     if (e != hipSuccess) {

@@ -107,34 +107,43 @@ template<typename W>
 struct lds_layout {
     static constexpr uint32_t chunk_bytes = 32 * sizeof(W) + 16;
     static constexpr uint32_t cube_bytes = threads_per_hc * chunk_bytes;  // 18432 (f32) / 34816 (f64)
-    static constexpr uint32_t zero_bytes = 32 * sizeof(W);                // zero block for out-of-cube neighbours
-    NDZIP_DEV static uint32_t off(uint32_t k) { return k * static_cast<uint32_t>(sizeof(W)) + (k >> 5) * 16u; }
+    // Region holding the zero block that out-of-cube stencil neighbours read.  The block itself sits at
+    // zero_offset<Dims>() inside the region: the 16-byte slot (mod 256) that none of the in-cube lanes of the same
+    // 16-lane group touches in any of the stencil's neighbour reads (tools/ldsbench3.hip scans all 16 slots:
+    // f32 3D {3, 11}, f64 3D {7, 15} for rows y-1 / z-1,y-1; f32 2D {7, 14}, f64 2D {14, 15}).  With the block
+    // in slot 0 every neighbour read of the 3D stencil paid a 2-way conflict in each lane group.
+    static constexpr uint32_t zero_bytes = 32 * sizeof(W) + 256;
+    template<int Dims>
+    NDZIP_DEV static constexpr uint32_t zero_offset() {
+        return sizeof(W) == 8 ? 15 * 16 : Dims == 3 ? 3 * 16 : Dims == 2 ? 7 * 16 : 0;
+    }
+    NDZIP_DEV static constexpr uint32_t off(uint32_t k) { return k * static_cast<uint32_t>(sizeof(W)) + (k >> 5) * 16u; }
 };
 
 struct alignas(16) vec16 {
     uint32_t w[4];
 };
 
-// 16 bytes per lane from LDS as TWO 8-byte reads (the compiler fuses them into one ds_read2_b64).  Measured on
-// gfx950 (tools/ldsbench.hip, SQ_LDS_IDX_ACTIVE): ds_read2_b64 moves a wavefront's 1 KiB in 4 LDS cycles, a single
-// ds_read_b128 of the same bytes takes 16 -- with any lane stride, including the canonical contiguous one.
-struct alignas(8) vec8 {
-    uint32_t w[2];
-};
+// 16 bytes per lane from LDS in one ds_read_b128.  Ground truth on gfx950 (tools/ldsbench2.hip, inline-asm reads,
+// SQ_LDS_IDX_ACTIVE per wave-instruction): ds_read_b128 at 16-byte-aligned lane strides of 16 / 144 / 272 bytes = 4
+// (the peak: 16 lanes x 16 bytes per count), the equivalent ds_read2_b64 = 16, ds_read_b128 at an address that is
+// only 8-byte aligned = 64.  A b128 access is served in groups of 16 consecutive lanes over sixteen 16-byte slots
+// (address / 16 mod 16); two lanes of a group in the same slot at different addresses double the group's cost.
 NDZIP_DEV vec16 lds_read16(const char *p) {
-    // The LDS byte address is laundered through an empty asm so the compiler cannot prove 16-byte alignment and
-    // re-fuse the pair into one ds_read_b128; the explicit address-space casts keep it an LDS (ds_*) access.
+    // The address goes through an empty volatile asm: it pins the order of the reads (hipcc otherwise hoists all 24
+    // stencil reads to the top and the kernel spills -- a scratch reload waits vmcnt(0), i.e. for every prefetch load
+    // in flight); the address-space cast keeps it a ds_ access.
     using lds_char = const __attribute__((address_space(3))) char;
-    using lds_u64 = const __attribute__((address_space(3))) unsigned long long;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    using lds_vec = const __attribute__((address_space(3))) u32x4;
     uint32_t a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_char *) p));
     asm volatile("" : "+v"(a));
-    lds_u64 *q = reinterpret_cast<lds_u64 *>(static_cast<uintptr_t>(a));
-    const unsigned long long lo = q[0], hi = q[1];
+    const u32x4 q = *reinterpret_cast<lds_vec *>(static_cast<uintptr_t>(a));
     vec16 v;
-    v.w[0] = static_cast<uint32_t>(lo);
-    v.w[1] = static_cast<uint32_t>(lo >> 32);
-    v.w[2] = static_cast<uint32_t>(hi);
-    v.w[3] = static_cast<uint32_t>(hi >> 32);
+    v.w[0] = q.x;
+    v.w[1] = q.y;
+    v.w[2] = q.z;
+    v.w[3] = q.w;
     return v;
 }
 NDZIP_DEV void lds_write16(char *p, vec16 v) { *reinterpret_cast<vec16 *>(p) = v; }
@@ -144,12 +153,13 @@ NDZIP_DEV W lds_read(const char *base, uint32_t byte_off) {
     return *reinterpret_cast<const W *>(base + byte_off);
 }
 
-// 16 consecutive values starting at value index k (k % 16 == 0, so the run never crosses a pad)
-template<typename W>
-NDZIP_DEV void read_run16(const char *p, W (&dst)[16]) {
+// N consecutive values from a 16-byte aligned LDS address that does not cross a chunk pad (N * sizeof(W) % 16 == 0)
+template<typename W, int N>
+NDZIP_DEV void read_run(const char *p, W (&dst)[N]) {
     constexpr int per = 16 / sizeof(W);  // values per 16-byte read
+    static_assert(N % per == 0, "whole 16-byte vectors only");
 #pragma unroll
-    for (int i = 0; i < 16 / per; ++i) {
+    for (int i = 0; i < N / per; ++i) {
         const vec16 v = lds_read16(p + 16 * i);
         if constexpr (sizeof(W) == 4) {
 #pragma unroll
@@ -159,6 +169,11 @@ NDZIP_DEV void read_run16(const char *p, W (&dst)[16]) {
             dst[2 * i + 1] = static_cast<uint64_t>(v.w[2]) | (static_cast<uint64_t>(v.w[3]) << 32);
         }
     }
+}
+
+template<typename W>
+NDZIP_DEV void read_run16(const char *p, W (&dst)[16]) {
+    read_run<W, 16>(p, dst);
 }
 
 template<typename W>
@@ -327,9 +342,12 @@ NDZIP_DEV void stage_hypercube_regs(const input_regs<W, Aligned> &regs, char *cu
     using L = lds_layout<W>;
     using R = input_regs<W, Aligned>;
     if constexpr (Aligned) {
+        // vector i sits at value (i*128 + t) * VE; 128 * VE values are whole padded chunks, so the LDS address is one
+        // per-lane base plus a compile-time step (an immediate offset of ds_write_b128, not eight address registers)
+        char *base = cube + L::off(static_cast<uint32_t>(t) * R::VE);
+        constexpr uint32_t step = L::off(threads_per_hc * R::VE);
 #pragma unroll
         for (int i = 0; i < R::NV; ++i) {
-            const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * R::VE;
             vec16 r;
             if constexpr (sizeof(W) == 4) {
 #pragma unroll
@@ -343,7 +361,7 @@ NDZIP_DEV void stage_hypercube_regs(const input_regs<W, Aligned> &regs, char *cu
                     r.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
                 }
             }
-            lds_write16(cube + L::off(k), r);
+            lds_write16(base + i * step, r);
         }
     } else {
 #pragma unroll
@@ -374,66 +392,82 @@ NDZIP_DEV void stencil_residuals(const char *cube, const char *zero, int t, type
         for (int j = 31; j >= 1; --j) r[j] = o[j] - o[j - 1];
         r[0] = o[0] - prev;
     } else if constexpr (Dims == 2) {
-        // chunk = half a row: y = t / 2, h = t % 2
+        // chunk = half a row: y = t / 2, h = t % 2; folded in two runs of 16 values (two runs live at a time)
         const int y = t >> 1, h = t & 1;
-        W o[32], u[32];
-        read_run16<W>(own, *reinterpret_cast<W(*)[16]>(&o[0]));
-        read_run16<W>(own + 16 * sizeof(W), *reinterpret_cast<W(*)[16]>(&o[16]));
         const char *up = y > 0 ? cube + L::off(k0 - 64) : zero;
-        read_run16<W>(up, *reinterpret_cast<W(*)[16]>(&u[0]));
-        read_run16<W>(up + 16 * sizeof(W), *reinterpret_cast<W(*)[16]>(&u[16]));
         const W ol = lds_read<W>(h ? cube + L::off(k0 - 1) : zero, 0);
         const W ul = lds_read<W>((h && y > 0) ? cube + L::off(k0 - 65) : zero, 0);
+        W left = ol - ul;  // y difference at x - 1
 #pragma unroll
-        for (int j = 0; j < 32; ++j) o[j] -= u[j];  // y difference
-        const W dl = ol - ul;
+        for (int q = 0; q < 2; ++q) {
+            W o[16], u[16];
+            read_run<W, 16>(own + q * 16 * sizeof(W), o);
+            read_run<W, 16>(up + q * 16 * sizeof(W), u);
 #pragma unroll
-        for (int j = 31; j >= 1; --j) r[j] = o[j] - o[j - 1];  // x difference
-        r[0] = o[0] - dl;
+            for (int j = 0; j < 16; ++j) o[j] -= u[j];  // y difference
+#pragma unroll
+            for (int j = 15; j >= 1; --j) r[16 * q + j] = o[j] - o[j - 1];  // x difference
+            r[16 * q] = o[0] - left;
+            left = o[15];
+            __builtin_amdgcn_sched_barrier(0);
+        }
     } else {
         // chunk = rows (z, y0) and (z, y0 + 1): z = t / 8, y0 = 2 * (t % 8)
         const int z = t >> 3, yp = t & 7;
-        // Rows are fetched and folded in small groups with scheduling barriers in between: left alone the
-        // scheduler issues all 24 ds_read_b128 up front, which costs ~70 extra VGPRs and a wavefront of occupancy.
-        W a[16], b[16];
-        read_run16<W>(own, a);
-        read_run16<W>(own + 16 * sizeof(W), b);
+        const char *row_p = yp > 0 ? cube + L::off(k0 - 16) : zero;                   // (z, y0-1)
+        const char *row_a1 = z > 0 ? cube + L::off(k0 - 256) : zero;                  // (z-1, y0)
+        const char *row_b1 = z > 0 ? row_a1 + 16 * sizeof(W) : zero;                  // (z-1, y0+1)
+        const char *row_p1 = (z > 0 && yp > 0) ? cube + L::off(k0 - 256 - 16) : zero; // (z-1, y0-1)
+        // The two rows are folded in halves of 8 values with scheduling barriers in between: at most four half-rows
+        // are live at a time.  Left alone the scheduler issues all 24 16-byte reads up front; as whole rows the fold
+        // needed ~30 more VGPRs at its peak, which (next to the previous tile's 32 plane words) spilled -- and a scratch
+        // reload waits vmcnt(0), i.e. for every prefetch load in flight.
+        constexpr int H = 8;
+        W carry_a = 0, carry_b = 0;  // last value of the previous half (x - 1 of this half's first value)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) b[j] -= a[j];  // row y0+1 minus row y0
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            W p[16];
-            read_run16<W>(yp > 0 ? cube + L::off(k0 - 16) : zero, p);
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t o = h * H * sizeof(W);
+            W a[H], b[H];
+            read_run<W, H>(own + o, a);
+            read_run<W, H>(own + 16 * sizeof(W) + o, b);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] -= p[j];  // row y0 minus row y0-1
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            W a1[16];
-            const char *below = z > 0 ? cube + L::off(k0 - 256) : zero;
-            read_run16<W>(below, a1);
+            for (int j = 0; j < H; ++j) b[j] -= a[j];  // row y0+1 minus row y0
+            __builtin_amdgcn_sched_barrier(0);
             {
-                W b1[16];
-                read_run16<W>(z > 0 ? below + 16 * sizeof(W) : zero, b1);
+                W p[H];
+                read_run<W, H>(row_p + o, p);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) b[j] -= b1[j] - a1[j];
+                for (int j = 0; j < H; ++j) a[j] -= p[j];  // row y0 minus row y0-1
             }
             __builtin_amdgcn_sched_barrier(0);
             {
-                W p1[16];
-                read_run16<W>((z > 0 && yp > 0) ? cube + L::off(k0 - 256 - 16) : zero, p1);
+                W a1[H];
+                read_run<W, H>(row_a1 + o, a1);
+                {
+                    W b1[H];
+                    read_run<W, H>(row_b1 + o, b1);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) a[j] -= a1[j] - p1[j];
+                    for (int j = 0; j < H; ++j) b[j] -= b1[j] - a1[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    W p1[H];
+                    read_run<W, H>(row_p1 + o, p1);
+#pragma unroll
+                    for (int j = 0; j < H; ++j) a[j] -= a1[j] - p1[j];
+                }
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 15; j >= 1; --j) {
-            r[j] = a[j] - a[j - 1];
-            r[16 + j] = b[j] - b[j - 1];
+            for (int j = H - 1; j >= 1; --j) {
+                r[h * H + j] = a[j] - a[j - 1];
+                r[16 + h * H + j] = b[j] - b[j - 1];
+            }
+            r[h * H] = a[0] - carry_a;
+            r[16 + h * H] = b[0] - carry_b;
+            carry_a = a[H - 1];
+            carry_b = b[H - 1];
         }
-        r[0] = a[0];
-        r[16] = b[0];
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) r[j] = complement_negative(r[j]);

@@ -12,12 +12,18 @@ namespace ndzip_hip {
 // agent-scope 8-byte store, so the value is its own flag (no fences; MI355X guide section 6 G16 "R2").
 using tile_desc = unsigned long long;
 
+// Scratch behind the descriptors: 16 experiment counters, then one ticket counter per class, each in its own 128-byte
+// line (see max_ticket_classes in codec_launch.inl).  Sizes in tile_desc units.
+constexpr unsigned max_ticket_classes = 16;
+constexpr unsigned ticket_stride_words = 32;  // uint32 words between the counters of consecutive classes
+constexpr unsigned scratch_extra_descs = 16 + max_ticket_classes * ticket_stride_words / 2;
+
 struct compress_args {
     const void *in;        // device, value_type[num_elements]
     grid_geom gg;
     uint32_t *header;      // device, NHC uint32 entries (+1 pad entry for 64-bit streams with odd NHC)
     void *body;            // device, first body word (= stream + header words for a contiguous stream)
-    tile_desc *desc;       // device scratch, >= num_tiles entries, zeroed by the launcher on `stream`
+    tile_desc *desc;       // device scratch, >= num_tiles + scratch_extra_descs entries, zeroed by the launcher on `stream`
     uint32_t *out_len;     // device scalar or nullptr
     uint32_t len_extra;    // header words + border words, added to the body length for *out_len
     uint32_t *err;         // device error word (sticky)

@@ -116,6 +116,42 @@ template<bool Preloaded>
 NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane,
         const lookback_windows &pre, uint32_t *hop_count = nullptr, uint32_t *poll_count = nullptr) {
     if (tile == 0) return 0;
+    if constexpr (Preloaded) {
+        // Fast path, no memory operation and therefore no s_waitcnt: the preloaded windows reach an inclusive prefix
+        // and every nearer descriptor is published.  (gfx9 counts loads and stores in one vmcnt and hipcc waits
+        // vmcnt(0) around the general loop below -- with this wavefront's aggregate store or prefetch loads in flight
+        // that wait costs a full memory round trip, 6-9k cycles per iteration, measured.)
+        uint32_t sum = 0;
+        bool complete = true, done = false;
+#pragma unroll
+        for (int j = 0; j < lookback_prefetch; ++j) {
+            const tile_desc d = pre.d[j];
+            const uint32_t status = static_cast<uint32_t>(d >> 32);
+            const unsigned long long invalid = __ballot(status == 0);
+            const unsigned long long inclusive = __ballot(status == 2);
+            if (complete && !done) {
+                if (inclusive != 0) {
+                    const int lf = __builtin_ctzll(inclusive);
+                    const unsigned long long nearer = lf == 0 ? 0ull : (~0ull >> (64 - lf));
+                    if ((invalid & nearer) == 0) {
+                        sum += wave_sum(lane <= lf ? static_cast<uint32_t>(d) : 0u);
+                        done = true;
+                    } else {
+                        complete = false;
+                    }
+                } else if (invalid == 0) {
+                    sum += wave_sum(static_cast<uint32_t>(d));  // (skip lanes carry value 0)
+                } else {
+                    complete = false;
+                }
+            }
+        }
+        if (done) {
+            if (lane == 0) desc_store(desc + tile, st_inclusive | (sum + aggregate));
+            return sum;
+        }
+    }
+    if (hop_count) *hop_count += 100;  // (experiments: general path taken)
     uint32_t exclusive = 0;
     long long base = static_cast<long long>(tile) - 1;
     bool timed_out = false;
@@ -201,7 +237,7 @@ template<int S, int Threads>
 NDZIP_DEV void copy_vectors(const vec16 *__restrict__ a, vec16 *__restrict__ d16, uint32_t nvec, int tid) {
     const char *base = reinterpret_cast<const char *>(a);
     for (uint32_t v = tid; v < nvec; v += Threads) {
-        const vec16 lo = lds_read16(base + 16 * v);  // ds_read2_b64, see lds_read16
+        const vec16 lo = lds_read16(base + 16 * v);
         if constexpr (S == 0) {
             d16[v] = lo;
         } else {
@@ -231,9 +267,11 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
 
 // Tiles are handed out dynamically: `num_classes` ticket counters (class = blockIdx % num_classes, ticket n of class c
 // is tile n * num_classes + c), so tile order == start order, a tile's predecessors were all started before it, and
-// the look-back never depends on co-residency, dispatch order or placement.  Several counters because one word
-// saturates at ~88 returning atomics per microsecond on this part and a 512^3 grid needs ~80 tickets per microsecond.
-constexpr uint32_t max_ticket_classes = 16;
+// the look-back never depends on co-residency, dispatch order or placement.
+// Several counters, EACH IN ITS OWN CACHE LINE: returning atomics on one line serialise in its L2 channel at ~80-90 per
+// microsecond in total -- no matter how many words of the line they target -- and a 512^3 grid wants ~150 tickets per
+// microsecond.  With 16 counters packed into one line the ticket rate capped the whole kernel (tools/membench2.hip:
+// the bare load loop 0.211 ms vs 0.101 ms with the counters 64+ bytes apart; static assignment 0.114 ms).
 
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (tile_cfg<T, Dims>::min_waves_per_simd))
@@ -253,22 +291,23 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
     const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
     const int lane = tid & 63, wave = tid >> 6;
     char *cube = smem + grp * L::cube_bytes;        // staging of this group's hypercube
-    char *zero = smem + K * L::cube_bytes;
-    uint32_t *misc = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
+    char *zero_region = smem + K * L::cube_bytes;
+    char *zero = zero_region + L::template zero_offset<Dims>();
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);              // the K encoded runs, back to back
 
-    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero)[i] = 0;
+    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
 
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
     const uint32_t cls = blockIdx.x % num_classes;
-    uint32_t *ticket_counter = tickets + cls;
+    uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
     if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
     __syncthreads();  // (also orders the zero block before the first stencil read)
     uint32_t tile = misc[NW + 1] * num_classes + cls;
 
 #ifdef NDZIP_EXP_PHASE_TIMING
     const bool timing = (exp_flags & 16u) != 0;
-    uint32_t ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t ticks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_prev = timing ? __builtin_readcyclecounter() : 0;
 #define NDZIP_PHASE(i)                                          \
     if (timing) {                                               \
@@ -371,8 +410,8 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
     if (timing && tid == 0) {
         unsigned long long *acc = desc + ntiles;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
-        atomicAdd(acc + 8, 1ull);
+        for (int i = 0; i < 12; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
+        atomicAdd(acc + 15, 1ull);
     }
 #endif
 }
@@ -422,22 +461,24 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     const int lane = tid & 63, wave = tid >> 6;
     char *cube = smem + grp * L::cube_bytes;                              // staging of this group's hypercube
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);             // later: the K encoded runs, back to back
-    char *zero = smem + K * L::cube_bytes;
-    uint32_t *misc = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
+    char *zero_region = smem + K * L::cube_bytes;
+    char *zero = zero_region + L::template zero_offset<Dims>();
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
 
-    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero)[i] = 0;
+    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
     stagger_start(exp_flags >> 8);
 
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
     const uint32_t cls = blockIdx.x % num_classes;
-    uint32_t *ticket_counter = tickets + cls;
+    uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
     if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
     uint32_t tile = misc[NW + 1] * num_classes + cls;
 
 #ifdef NDZIP_EXP_PHASE_TIMING
     const bool timing = (exp_flags & 16u) != 0;
-    uint32_t ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t ticks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t tick_dummy[2] = {0, 0};
     uint64_t t_prev = timing ? __builtin_readcyclecounter() : 0;
 #define NDZIP_PHASE(i)                                          \
     if (timing) {                                               \
@@ -466,6 +507,11 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (!have_cur && !have_prev) break;
         const uint32_t hc = tile * K + grp;
         const bool active = have_cur && hc < gg.nhc;
+        // The previous tile's look-back window, issued together with the ticket: both return while this wavefront
+        // waits for its prefetched input anyway, so the window is in registers before any other memory operation of
+        // the iteration is issued and the resolve below needs no wait.
+        lookback_windows window{};
+        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         if (have_cur) {
             uint32_t next_ticket = 0;
             if (tid == 0) next_ticket = atomicAdd(ticket_counter, 1u);
@@ -475,9 +521,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         NDZIP_PHASE(0)  // ticket + wait prefetch + stage
         __syncthreads();  // B1: cube staged, next ticket known
         const uint32_t next_tile = have_cur ? misc[NW + 1] * num_classes + cls : tile;
-        lookback_windows window{};
-        __builtin_amdgcn_sched_barrier(0);
-        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t next_hc = next_tile * K + grp;
         if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
@@ -498,12 +541,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         }
         NDZIP_PHASE(2)  // stencil + head + chunk scan
         __syncthreads();  // B2: all stencil reads done (staging region reusable), wave totals known
-        // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
-        // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
-        // live around the whole loop.
-        __builtin_amdgcn_sched_barrier(0);
-        load_hypercube_regs<T, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
-        __builtin_amdgcn_sched_barrier(0);
+        NDZIP_PHASE(8)  // B2 wait
         uint32_t run_start = 0, aggregate = 0, my_len = 0, chunk_excl = 0;
         if (have_cur) {
 #pragma unroll
@@ -516,6 +554,28 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             chunk_excl = ((wave & 1) ? misc[2 * grp] : 0u) + incl - count;
             if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
+        NDZIP_PHASE(9)  // aggregate + publish
+        // The previous tile's prefix, BEFORE this wavefront's late prefetch is issued: vector memory operations retire
+        // in order and hipcc waits vmcnt(0) around the descriptor loop, so a resolve placed after the prefetch would
+        // sit out the whole HBM latency of those six loads (measured: 5.8k of the 26k cycles of an iteration).  The
+        // window was read at the top of the iteration and has long arrived.
+        if (have_prev && wave == 0) {
+            const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
+#ifdef NDZIP_EXP_PHASE_TIMING
+                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window, &ticks[10], &ticks[11]);
+#else
+                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
+#endif
+            if (tid == 0) misc[NW] = exclusive;
+        }
+        NDZIP_PHASE(6)  // B2 + publish + resolve (prev)
+        // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
+        // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
+        // live around the whole loop.
+        __builtin_amdgcn_sched_barrier(0);
+        load_hypercube_regs<T, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
+        __builtin_amdgcn_sched_barrier(0);
+        NDZIP_PHASE(7)  // late prefetch issue
         if (have_prev) {
             // the previous tile's planes leave the registers: compact them into the (now free) staging region
             if (prev_active && !(exp_flags & 4u)) {
@@ -527,17 +587,8 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
                     if (planes[i] != 0) run[pos++] = planes[i];
                 }
             }
-            if (wave == 0) {
-                const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
-#ifdef NDZIP_EXP_PHASE_TIMING
-                                                            : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window, &ticks[6], &ticks[7]);
-#else
-                                                            : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
-#endif
-                if (tid == 0) misc[NW] = exclusive;
-            }
         }
-        NDZIP_PHASE(3)  // B2 + publish + plane writes (prev) + resolve (prev)
+        NDZIP_PHASE(3)  // plane writes (prev)
         __syncthreads();  // B3: previous tile's runs complete in LDS, its prefix known
         if (have_prev) {
             const uint32_t prefix = misc[NW];
@@ -572,8 +623,8 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     if (timing && tid == 0) {
         unsigned long long *acc = desc + ntiles;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
-        atomicAdd(acc + 8, 1ull);
+        for (int i = 0; i < 12; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
+        atomicAdd(acc + 15, 1ull);
     }
 #endif
 }
@@ -648,10 +699,11 @@ debug_stage_kernel(int stage, const grid_geom gg, uint32_t hc, const typename wo
     using L = lds_layout<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *cube = smem;
-    char *zero = smem + L::cube_bytes;
-    uint32_t *xchg = reinterpret_cast<uint32_t *>(zero + L::zero_bytes);
+    char *zero_region = smem + L::cube_bytes;
+    char *zero = zero_region + L::template zero_offset<Dims>();
+    uint32_t *xchg = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);
     const int t = static_cast<int>(threadIdx.x);
-    for (uint32_t i = t; i < L::zero_bytes / 4; i += threads_per_hc) reinterpret_cast<uint32_t *>(zero)[i] = 0;
+    for (uint32_t i = t; i < L::zero_bytes / 4; i += threads_per_hc) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
 
     W r[vals_per_thread];
     if (stage == debug_forward_transform) {
@@ -726,21 +778,21 @@ hipError_t launch_compress_profile(const compress_args &a) {
     static const int exp_bpc = getenv("NDZIP_HIP_BPC") ? atoi(getenv("NDZIP_HIP_BPC")) : 0;
     uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(exp_bpc > 0 && exp_bpc < blocks_per_cu ? exp_bpc : blocks_per_cu);
     if (grid > ntiles) grid = ntiles;
-    // scratch layout: [ntiles descriptors][16 x u64 experiment counters][max_ticket_classes x u32 ticket counters]
-    hipError_t e = hipMemsetAsync(a.desc, 0, (static_cast<size_t>(ntiles) + 16 + max_ticket_classes / 2) * sizeof(tile_desc), a.stream);
+    // scratch layout: [ntiles descriptors][16 x u64 experiment counters][max_ticket_classes ticket counters, one per 128 B]
+    hipError_t e = hipMemsetAsync(a.desc, 0, (static_cast<size_t>(ntiles) + scratch_extra_descs) * sizeof(tile_desc), a.stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg,
             a.header, static_cast<W *>(a.body), a.desc, reinterpret_cast<uint32_t *>(a.desc + ntiles + 16),
             grid >= max_ticket_classes ? max_ticket_classes : 1u, a.out_len, a.len_extra, a.err, exp_flags);
     if (exp_flags & 16u) {  // experiments only: dump the per-phase cycle totals of this launch
-        unsigned long long acc[9];
+        unsigned long long acc[16];
         (void) hipStreamSynchronize(a.stream);
         (void) hipMemcpy(acc, a.desc + ntiles, sizeof acc, hipMemcpyDeviceToHost);
         static int dumps = 0;
         if (dumps++ % 8 == 4) {
-            const double n = static_cast<double>(acc[8] ? acc[8] : 1) * ((ntiles + grid - 1) / grid);
-            fprintf(stderr, "[phase ticks per iteration, avg over %llu workgroups]", acc[8]);
-            for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.0f", i, static_cast<double>(acc[i]) / n);
+            const double n = static_cast<double>(acc[15] ? acc[15] : 1) * ((ntiles + grid - 1) / grid);
+            fprintf(stderr, "[phase ticks per iteration, avg over %llu workgroups]", acc[15]);
+            for (int i = 0; i < 12; ++i) fprintf(stderr, " p%d=%.0f", i, static_cast<double>(acc[i]) / n);
             fprintf(stderr, "\n");
         }
     }
