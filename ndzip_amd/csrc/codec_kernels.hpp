@@ -148,6 +148,53 @@ NDZIP_DEV vec16 lds_read16(const char *p) {
 }
 NDZIP_DEV void lds_write16(char *p, vec16 v) { *reinterpret_cast<vec16 *>(p) = v; }
 
+// 16 / 8 bytes per lane from / to GLOBAL memory.  Aligned = the address is a multiple of the access size; otherwise only
+// of the element size (a row of an array whose extent is not a multiple of 4 elements starts anywhere): gfx950 runs in
+// unaligned access mode, so this is still ONE global_load/store_dwordx4 per lane -- it may touch one cache line more per
+// row, nothing like the 4-byte-per-lane accesses of a scalar path.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) unaligned16 {
+    u32x4_t v;
+};
+struct __attribute__((packed, aligned(4))) unaligned8 {
+    u32x2_t v;
+};
+template<bool Aligned>
+NDZIP_DEV vec16 global_load16(const void *p) {
+    if constexpr (Aligned) {
+        return *reinterpret_cast<const vec16 *>(p);
+    } else {
+        const u32x4_t q = reinterpret_cast<const unaligned16 *>(p)->v;
+        vec16 v;
+        v.w[0] = q.x;
+        v.w[1] = q.y;
+        v.w[2] = q.z;
+        v.w[3] = q.w;
+        return v;
+    }
+}
+template<bool Aligned>
+NDZIP_DEV void global_store16(void *p, const vec16 &v) {
+    if constexpr (Aligned) {
+        *reinterpret_cast<vec16 *>(p) = v;
+    } else {
+        unaligned16 u;
+        u.v = u32x4_t{v.w[0], v.w[1], v.w[2], v.w[3]};
+        *reinterpret_cast<unaligned16 *>(p) = u;
+    }
+}
+template<bool Aligned>
+NDZIP_DEV void global_store8(void *p, uint32_t a, uint32_t b) {
+    if constexpr (Aligned) {
+        *reinterpret_cast<uint2 *>(p) = make_uint2(a, b);
+    } else {
+        unaligned8 u;
+        u.v = u32x2_t{a, b};
+        *reinterpret_cast<unaligned8 *>(p) = u;
+    }
+}
+
 template<typename W>
 NDZIP_DEV W lds_read(const char *base, uint32_t byte_off) {
     return *reinterpret_cast<const W *>(base + byte_off);
@@ -303,8 +350,7 @@ template<typename W, bool Aligned>
 struct input_regs {
     static constexpr int VE = 16 / sizeof(W);                  // values per 16-byte vector
     static constexpr int NV = hc_size / VE / threads_per_hc;   // 8 (f32) / 16 (f64) vectors per work-item
-    vec16 v[Aligned ? NV : 1];
-    W s[Aligned ? 1 : vals_per_thread];
+    vec16 v[NV];
 };
 
 // phase 0a: issue the coalesced global loads of hypercube `origin` (nothing waits here)
@@ -316,24 +362,15 @@ NDZIP_DEV void load_hypercube_regs(const typename profile<T, Dims>::word *__rest
         uint64_t origin, int t, input_regs<typename profile<T, Dims>::word, Aligned> &regs) {
     using W = typename profile<T, Dims>::word;
     using R = input_regs<W, Aligned>;
-    constexpr int n = Aligned ? R::NV : vals_per_thread;
-    constexpr int split = Aligned ? Split : Split * (vals_per_thread / R::NV);
-    constexpr int first = Part == 1 ? split : 0;
-    constexpr int last = Part == 0 ? split : n;
+    constexpr int first = Part == 1 ? Split : 0;
+    constexpr int last = Part == 0 ? Split : R::NV;
     // vector i of work-item t covers cube-local values k_i = (i*128 + t) * VE; 128*VE values are a whole number of
-    // rows / planes, so the global offset is affine in i: one per-lane base plus a uniform step.
-    if constexpr (Aligned) {
-        const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
-        const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE);
+    // rows / planes, so the global offset is affine in i: one per-lane base plus a uniform step.  A vector never
+    // crosses a hypercube row (VE divides the side length), so the same path serves unaligned rows.
+    const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
+    const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE);
 #pragma unroll
-        for (int i = first; i < last; ++i) regs.v[i] = *reinterpret_cast<const vec16 *>(base + i * step);
-    } else {
-        // scalar path for unaligned extents: 128 values are half a 3D plane, so the offset is NOT affine in i
-#pragma unroll
-        for (int i = first; i < last; ++i) {
-            regs.s[i] = in[origin + local_offset<Dims>(gg, static_cast<uint32_t>(i * threads_per_hc + t))];
-        }
-    }
+    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned>(base + i * step);
 }
 
 // phase 0b: rotl1 and store to the padded LDS staging layout
@@ -341,7 +378,7 @@ template<typename W, bool Aligned>
 NDZIP_DEV void stage_hypercube_regs(const input_regs<W, Aligned> &regs, char *cube, int t) {
     using L = lds_layout<W>;
     using R = input_regs<W, Aligned>;
-    if constexpr (Aligned) {
+    {
         // vector i sits at value (i*128 + t) * VE; 128 * VE values are whole padded chunks, so the LDS address is one
         // per-lane base plus a compile-time step (an immediate offset of ds_write_b128, not eight address registers)
         char *base = cube + L::off(static_cast<uint32_t>(t) * R::VE);
@@ -362,12 +399,6 @@ NDZIP_DEV void stage_hypercube_regs(const input_regs<W, Aligned> &regs, char *cu
                 }
             }
             lds_write16(base + i * step, r);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < vals_per_thread; ++i) {
-            const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
-            *reinterpret_cast<W *>(cube + L::off(k)) = rotl1(regs.s[i]);
         }
     }
 }
@@ -744,7 +775,7 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
     // ---- phase 3: remaining axis sums in the store layout, rotr1, coalesced global store ---------------------
     if (!active) return;
     if constexpr (Dims == 1) {
-        if constexpr (Aligned) {
+        {
             constexpr int VE = 16 / sizeof(W);
             constexpr int NV = hc_size / VE / threads_per_hc;
 #pragma unroll
@@ -762,13 +793,7 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
                         v.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
                     }
                 }
-                *reinterpret_cast<vec16 *>(out + origin + k) = v;
-            }
-        } else {
-#pragma unroll 4
-            for (int i = 0; i < vals_per_thread; ++i) {
-                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t);
-                out[origin + k] = rotr1(lds_read<W>(cube, L::off(k)));
+                global_store16<Aligned>(out + origin + k, v);
             }
         }
     } else if constexpr (Dims == 2) {
@@ -799,28 +824,18 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
                 const uint2 v = *reinterpret_cast<const uint2 *>(p);
                 acc0 += v.x;
                 acc1 += v.y;
-                if constexpr (Aligned) {
-                    *reinterpret_cast<uint2 *>(out + g) = make_uint2(rotr1(acc0), rotr1(acc1));
-                } else {
-                    out[g] = rotr1(acc0);
-                    out[g + 1] = rotr1(acc1);
-                }
+                global_store8<Aligned>(out + g, rotr1(acc0), rotr1(acc1));
             } else {
                 const vec16 v = lds_read16(p);
                 acc0 += static_cast<uint64_t>(v.w[0]) | (static_cast<uint64_t>(v.w[1]) << 32);
                 acc1 += static_cast<uint64_t>(v.w[2]) | (static_cast<uint64_t>(v.w[3]) << 32);
                 const uint64_t o0 = rotr1(acc0), o1 = rotr1(acc1);
-                if constexpr (Aligned) {
-                    vec16 w;
-                    w.w[0] = static_cast<uint32_t>(o0);
-                    w.w[1] = static_cast<uint32_t>(o0 >> 32);
-                    w.w[2] = static_cast<uint32_t>(o1);
-                    w.w[3] = static_cast<uint32_t>(o1 >> 32);
-                    *reinterpret_cast<vec16 *>(out + g) = w;
-                } else {
-                    out[g] = o0;
-                    out[g + 1] = o1;
-                }
+                vec16 w;
+                w.w[0] = static_cast<uint32_t>(o0);
+                w.w[1] = static_cast<uint32_t>(o0 >> 32);
+                w.w[2] = static_cast<uint32_t>(o1);
+                w.w[3] = static_cast<uint32_t>(o1 >> 32);
+                global_store16<Aligned>(out + g, w);
             }
         }
     }

@@ -29,7 +29,11 @@ using T_ = NDZIP_T;
 // lines of the 64-byte cube rows); f64 rows already are >= 128 bytes and the cube is twice as large in LDS.
 template<typename T, int Dims>
 struct tile_cfg {
+#ifdef NDZIP_EXP_K
+    static constexpr int K = sizeof(T) == 4 ? NDZIP_EXP_K : 1;
+#else
     static constexpr int K = sizeof(T) == 4 ? 2 : 1;
+#endif
     static constexpr int threads = K * threads_per_hc;
     using W = typename word_of<T>::type;
     using L = lds_layout<W>;
@@ -450,7 +454,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
 #ifdef NDZIP_EXP_EARLY_VECTORS
     constexpr int early_vectors = NDZIP_EXP_EARLY_VECTORS;
 #else
-    constexpr int early_vectors = 2;  // of 8; measured on 512^3: 0 -> 0.258 ms, 2 -> 0.245, 4 -> 0.254, 8 (spills) -> 0.34
+    constexpr int early_vectors = 4;  // of 8; measured on 512^3: 2 -> 0.221 ms, 4 -> 0.211, 6 -> 0.219 (spills)
 #endif
     constexpr int K = C::K;
     constexpr int NW = C::threads / 64;
@@ -555,20 +559,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
         NDZIP_PHASE(9)  // aggregate + publish
-        // The previous tile's prefix, BEFORE this wavefront's late prefetch is issued: vector memory operations retire
-        // in order and hipcc waits vmcnt(0) around the descriptor loop, so a resolve placed after the prefetch would
-        // sit out the whole HBM latency of those six loads (measured: 5.8k of the 26k cycles of an iteration).  The
-        // window was read at the top of the iteration and has long arrived.
-        if (have_prev && wave == 0) {
-            const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
-#ifdef NDZIP_EXP_PHASE_TIMING
-                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window, &ticks[10], &ticks[11]);
-#else
-                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
-#endif
-            if (tid == 0) misc[NW] = exclusive;
-        }
-        NDZIP_PHASE(6)  // B2 + publish + resolve (prev)
         // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
         // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
         // live around the whole loop.
@@ -589,6 +579,32 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             }
         }
         NDZIP_PHASE(3)  // plane writes (prev)
+        // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
+        if (have_cur) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) planes[j] = r[j];
+            transpose32(planes);
+        }
+        NDZIP_PHASE(5)  // transposes
+        __builtin_amdgcn_sched_barrier(0);
+        // The previous tile's prefix, as the LAST thing wavefront 0 does before B3: its predecessors (which may lag by
+        // a good part of an iteration) have had the most time to publish, and its own late prefetch, which hipcc's
+        // vmcnt(0) in the general loop also sits out (loads return in order), has been in flight the longest.  The
+        // window read at the top of the iteration settles the prefix without any memory operation in 1-2 of 10 cases.
+        // Measured alternatives (512^3 f32, ms): resolve before the late prefetch 0.211; look-back wavefront without
+        // prefetch in flight 0.219; window re-read behind B2 and consumed after the plane writes 0.217-0.224; whole
+        // resolve right behind B1 0.238 (0.3 polls per tile, convoys); resolve between late prefetch and plane writes
+        // 0.207; this order 0.201-0.205.
+        if (have_prev && wave == 0) {
+            const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
+#ifdef NDZIP_EXP_PHASE_TIMING
+                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window, &ticks[10], &ticks[11]);
+#else
+                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
+#endif
+            if (tid == 0) misc[NW] = exclusive;
+        }
+        NDZIP_PHASE(6)  // resolve (prev)
         __syncthreads();  // B3: previous tile's runs complete in LDS, its prefix known
         if (have_prev) {
             const uint32_t prefix = misc[NW];
@@ -599,13 +615,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             }
         }
         NDZIP_PHASE(4)  // B3 + copy-out (prev)
-        // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
-        if (have_cur) {
-#pragma unroll
-            for (int j = 0; j < 32; ++j) planes[j] = r[j];
-            transpose32(planes);
-        }
-        NDZIP_PHASE(5)  // transposes (+ B4 wait next)
         __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them
         have_prev = have_cur;
         prev_tile = tile;

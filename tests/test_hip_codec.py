@@ -88,6 +88,46 @@ def test_many_hypercubes_unaligned_and_aligned(hiplib, cuda_device, profile, kin
         assert same_bits(device_decompress(stream, dtype, shape), data)
 
 
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+@pytest.mark.parametrize("skew", [1, 3])
+def test_element_aligned_device_pointers(hiplib, cuda_device, profile, skew):
+    """Array, stream and output pointers that are only element-aligned (sub-views `skew` elements into an allocation):
+    the 16-byte global accesses of the kernels must not assume more (the reference takes any T* / bits_type*)."""
+    import torch
+
+    import ndzip_amd
+    from ndzip_amd.synth import synth_numpy
+
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 3 + 5,), 2: (side * 2 + 3, side * 3), 3: (side * 2, side + 3, side * 2 + 1)}[dims]
+    data = synth_numpy(shape, dtype, seed=77 + skew, noise_mask=0xFF)
+    expect = oracle.compress(data)
+    n = data.size
+    wdt = torch.int32 if np.dtype(dtype) == np.float32 else torch.int64
+    ndt = np.int32 if np.dtype(dtype) == np.float32 else np.int64
+    bound = ndzip_amd.compressed_length_bound(dtype, shape)
+    d_in_alloc = torch.zeros(n + 8, dtype=wdt, device=cuda_device)
+    d_in = d_in_alloc[skew: skew + n]
+    d_in.copy_(torch.from_numpy(data.reshape(-1).view(ndt)))
+    d_stream = torch.zeros(bound + 8, dtype=wdt, device=cuda_device)[skew: skew + bound]
+    d_len = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    comp = ndzip_amd.make_hip_compressor(dtype, ndzip_amd.CompressorRequirements(shape), stream)
+    comp.compress(d_in, shape, d_stream, d_len)
+    comp.check()
+    words = int(d_len.cpu().numpy().view(np.uint32)[0])
+    got = d_stream[:words].cpu().numpy().view(expect.dtype)
+    assert words == len(expect) and np.array_equal(got, expect)
+    d_out = torch.zeros(n + 8, dtype=wdt, device=cuda_device)[skew: skew + n]
+    dec = ndzip_amd.make_hip_decompressor(dtype, dims, stream)
+    dec.decompress(d_stream, d_out, shape)
+    dec.check()
+    assert same_bits(d_out.cpu().numpy().view(dtype).reshape(shape), data)
+    comp.close()
+    dec.close()
+
+
 def test_f64_odd_hypercube_count_zeroes_header_pad(hiplib, cuda_device):
     # SURVEY 8a: 1D f64 3x4096 zeros -> len 194, header {0x40, 0x80, 0xc0, pad 0}
     data = np.zeros(3 * 4096, dtype=np.float64)
