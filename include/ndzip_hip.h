@@ -137,6 +137,42 @@ NDZIP_HIP_API int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t
 NDZIP_HIP_API int ndzip_hip_offload_decompress(int dtype, int dims, const uint32_t *extent, const void *stream,
         uint32_t stream_length_words, void *data, uint32_t *words_consumed, uint64_t *kernel_ns);
 
+/* ---- persistent, pipelined host-pointer interface -------------------------------------------------------------
+ * What an `offloader<T>` OBJECT is in the reference (include/ndzip/offload.hh:8-34: created once by make_offloader,
+ * called per array) for callers that stream many arrays through the device -- the CLI's chunk loop
+ * (src/compress/compress.cc:17-86) and the interconnect use case of README.md:13-14.  The handle owns `slots` job slots;
+ * each slot has its own HIP stream, device input / stream / length buffers sized for `max_extent`, and codec handles, so
+ * the H2D copy of job j+1, the kernels of job j and the D2H copy of job j-1 overlap.  Host buffers should come from
+ * ndzip_hip_host_alloc (pinned: asynchronous DMA); pageable pointers work but the copies then serialise.
+ * A slot is busy from submit until wait; one thread drives a handle. */
+typedef struct ndzip_hip_offloader ndzip_hip_offloader;
+
+NDZIP_HIP_API int ndzip_hip_offloader_create(int dtype, int dims, const uint32_t *max_extent, int slots, ndzip_hip_offloader **out);
+NDZIP_HIP_API int ndzip_hip_offloader_destroy(ndzip_hip_offloader *o);
+
+/* pinned host memory (hipHostMalloc / hipHostFree) */
+NDZIP_HIP_API int ndzip_hip_host_alloc(size_t bytes, void **ptr);
+NDZIP_HIP_API int ndzip_hip_host_free(void *ptr);
+
+/* enqueue offloader<T>::compress(data, extent, stream) on `slot`: returns at once; `data` and `stream`
+ * (compressed_length_bound words) must stay valid until the wait */
+NDZIP_HIP_API int ndzip_hip_offloader_submit_compress(ndzip_hip_offloader *o, int slot, const uint32_t *extent, const void *data,
+        void *stream);
+/* enqueue offloader<T>::decompress(stream, length, data, extent) on `slot` */
+NDZIP_HIP_API int ndzip_hip_offloader_submit_decompress(ndzip_hip_offloader *o, int slot, const uint32_t *extent,
+        const void *stream, uint32_t stream_length_words, void *data);
+/* complete the job of `slot`: *words = the reference call's return value (stream length / words consumed), *kernel_ns =
+ * device pipeline time by events (either may be NULL).  For a compress job the stream's D2H copy happens here, once the
+ * length is known, on the slot's own stream. */
+NDZIP_HIP_API int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, uint64_t *kernel_ns);
+
+/* Words of the stream of an array of `extent` that starts at HOST pointer `stream`: header + last offset + border
+ * (what decompress returns, cuda_codec.inl:740-745), from the header alone -- lets a reader split a file of concatenated
+ * streams (src/compress/compress.cc:62-86) before decompressing.  `available_words`: how many words `stream` holds;
+ * fails with NDZIP_HIP_ERR_INVALID_ARGUMENT if the header itself or the implied stream does not fit. */
+NDZIP_HIP_API int ndzip_hip_stream_words(int dtype, int dims, const uint32_t *extent, const void *stream, uint64_t available_words,
+        uint32_t *words);
+
 /* ---- stage entry points (parity tests; mirror the reference's stage-level tests
  *      src/test/codec_profile_test.inl:514-549, :552-729, :735-801, :889-947) ----------------------------------- */
 

@@ -3,6 +3,7 @@
 Layout:
   csrc/        hand-written HIP kernels + the C ABI (built in-tree into libndzip_hip.so by ndzip_amd.build)
   hip.py       Python mirror of the reference's compressor / decompressor / offloader interfaces (ctypes)
+  cli/         `ndzip-hip`: file-level compress / decompress tool (the reference's src/compress for this back-end)
   sharded.py   multi-GPU hypercube-range sharding (one process per GPU, RCCL only for offsets + headers)
   synth.py     deterministic integer-only synthetic grids
 """
@@ -11,6 +12,8 @@ from .hip import (  # noqa: F401
     HipCompressor,
     HipDecompressor,
     HipOffloader,
+    HipPipelinedOffloader,
+    PinnedBuffer,
     NdzipHipError,
     compressed_length_bound,
     device_info,
@@ -19,5 +22,6 @@ from .hip import (  # noqa: F401
     make_hip_decompressor,
     make_hip_offloader,
     num_hypercubes,
+    stream_words,
     word_dtype,
 )

@@ -53,7 +53,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs])
+    build_cli(force=force, verbose=verbose)
     return OUT
+
+
+CLI_SRC = os.path.join(HERE, "cli", "ndzip_hip_cli.cc")
+CLI_OUT = os.path.join(HERE, "ndzip-hip")
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> str:
+    """The file-level tool (plain C++ over the C ABI, no HIP headers): ndzip_amd/ndzip-hip, next to the library it loads."""
+    if force or _stale(CLI_OUT, [CLI_SRC, OUT, os.path.join(HERE, "..", "include", "ndzip_hip.h")]):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", CLI_OUT, CLI_SRC, "-L" + HERE, "-lndzip_hip",
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return CLI_OUT
 
 
 if __name__ == "__main__":

@@ -502,6 +502,214 @@ int ndzip_hip_offload_decompress(int dtype, int dims, const uint32_t *extent, co
     return NDZIP_HIP_OK;
 }
 
+// ---- persistent, pipelined host-pointer interface ---------------------------------------------------------------
+
+}  // extern "C"
+
+namespace {
+struct offload_slot {
+    hipStream_t stream = nullptr;
+    void *d_array = nullptr;    // raw array (input of compress, output of decompress)
+    void *d_stream = nullptr;   // compressed stream, length-bound words
+    uint32_t *d_len = nullptr;
+    uint32_t *h_len = nullptr;  // pinned
+    hipEvent_t start = nullptr, stop = nullptr;
+    ndzip_hip_compressor *comp = nullptr;
+    ndzip_hip_decompressor *decomp = nullptr;
+    int job = 0;  // 0 idle, 1 compress, 2 decompress
+    void *host_out = nullptr;
+    uint32_t words = 0;  // decompress: words consumed, known at submit
+};
+}  // namespace
+
+struct ndzip_hip_offloader {
+    int dtype;
+    int dims;
+    grid_geom max_gg;
+    size_t array_bytes;
+    size_t stream_bytes;
+    int nslots;
+    offload_slot *slots;
+};
+
+namespace {
+void destroy_offloader(ndzip_hip_offloader *o) {
+    if (!o) return;
+    for (int i = 0; i < o->nslots; ++i) {
+        offload_slot &s = o->slots[i];
+        if (s.stream) (void) hipStreamSynchronize(s.stream);
+        if (s.comp) ndzip_hip_compressor_destroy(s.comp);
+        if (s.decomp) ndzip_hip_decompressor_destroy(s.decomp);
+        if (s.d_array) (void) hipFree(s.d_array);
+        if (s.d_stream) (void) hipFree(s.d_stream);
+        if (s.d_len) (void) hipFree(s.d_len);
+        if (s.h_len) (void) hipHostFree(s.h_len);
+        if (s.start) (void) hipEventDestroy(s.start);
+        if (s.stop) (void) hipEventDestroy(s.stop);
+        if (s.stream) (void) hipStreamDestroy(s.stream);
+    }
+    delete[] o->slots;
+    delete o;
+}
+
+int slot_of(ndzip_hip_offloader *o, int slot, offload_slot **out, bool want_idle) {
+    if (!o) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle");
+    if (slot < 0 || slot >= o->nslots) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "slot out of range");
+    if (want_idle && o->slots[slot].job != 0) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "slot is busy: wait for it first");
+    if (!want_idle && o->slots[slot].job == 0) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "slot is idle: nothing to wait for");
+    *out = &o->slots[slot];
+    return NDZIP_HIP_OK;
+}
+
+int job_geometry(ndzip_hip_offloader *o, const uint32_t *extent, grid_geom *gg) {
+    if (!extent) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null extent");
+    *gg = make_geom(o->dims, extent);
+    if (int s = check_limits(o->dtype, *gg)) return s;
+    if (num_elements(*gg) * word_bytes(o->dtype) > o->array_bytes || length_bound(o->dtype, *gg) * word_bytes(o->dtype) > o->stream_bytes
+            || gg->nhc > o->max_gg.nhc) {
+        return fail(NDZIP_HIP_ERR_CAPACITY, "extent is larger than the offloader was created for");
+    }
+    return NDZIP_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ndzip_hip_offloader_create(int dtype, int dims, const uint32_t *max_extent, int slots, ndzip_hip_offloader **out) {
+    if (!out) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
+    *out = nullptr;
+    if (!valid_dtype(dtype) || !max_extent) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    if (slots < 1 || slots > 16) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "slots must be between 1 and 16");
+    if (int s = ensure_device(nullptr)) return s;
+    const grid_geom gg = make_geom(dims, max_extent);
+    if (int s = check_limits(dtype, gg)) return s;
+    auto *o = new ndzip_hip_offloader{dtype, dims, gg, static_cast<size_t>(num_elements(gg)) * word_bytes(dtype),
+            static_cast<size_t>(length_bound(dtype, gg)) * word_bytes(dtype), slots, new offload_slot[slots]};
+    for (int i = 0; i < slots; ++i) {
+        offload_slot &s = o->slots[i];
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&s.d_array, o->array_bytes ? o->array_bytes : 16);
+        if (e == hipSuccess) e = hipMalloc(&s.d_stream, o->stream_bytes ? o->stream_bytes : 16);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s.d_len), sizeof(uint32_t));
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_len), sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreate(&s.start);
+        if (e == hipSuccess) e = hipEventCreate(&s.stop);
+        int status = e == hipSuccess ? NDZIP_HIP_OK : fail_hip(e, "allocating offloader slot");
+        if (!status) status = ndzip_hip_compressor_create(dtype, dims, gg.nhc, s.stream, &s.comp);
+        if (!status) status = ndzip_hip_decompressor_create(dtype, dims, s.stream, &s.decomp);
+        if (status) {
+            destroy_offloader(o);
+            return status;
+        }
+    }
+    *out = o;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_offloader_destroy(ndzip_hip_offloader *o) {
+    destroy_offloader(o);
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null pointer");
+    *ptr = nullptr;
+    if (int s = ensure_device(nullptr)) return s;
+    HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_host_free(void *ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_offloader_submit_compress(ndzip_hip_offloader *o, int slot, const uint32_t *extent, const void *data, void *stream) {
+    offload_slot *s = nullptr;
+    if (int st = slot_of(o, slot, &s, true)) return st;
+    if (!stream) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null stream buffer");
+    grid_geom gg;
+    if (int st = job_geometry(o, extent, &gg)) return st;
+    const size_t in_bytes = static_cast<size_t>(num_elements(gg)) * word_bytes(o->dtype);
+    if (in_bytes && !data) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null input");
+    if (in_bytes) HIP_TRY(hipMemcpyAsync(s->d_array, data, in_bytes, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipEventRecord(s->start, s->stream));
+    if (int st = ndzip_hip_compressor_compress(s->comp, s->d_array, o->dims, extent, s->d_stream, s->d_len)) return st;
+    HIP_TRY(hipEventRecord(s->stop, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_len, s->d_len, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    s->job = 1;
+    s->host_out = stream;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_stream_words(int dtype, int dims, const uint32_t *extent, const void *stream, uint64_t available_words, uint32_t *words) {
+    if (!valid_dtype(dtype) || !extent || !words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    const grid_geom gg = make_geom(dims, extent);
+    if (num_elements(gg) > 0xffffffffull) return fail(NDZIP_HIP_ERR_LIMIT, "extent has more than 2^32-1 elements (index_type is uint32_t)");
+    const uint64_t hw = header_words_for(dtype, gg.nhc);
+    if (available_words < hw || (gg.nhc && !stream)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "stream shorter than its header");
+    const uint64_t last = gg.nhc ? static_cast<const uint32_t *>(stream)[gg.nhc - 1] : 0;
+    const uint64_t total = hw + last + border_count(gg);
+    const uint64_t B = dtype == NDZIP_HIP_F32 ? 32 : 64;
+    if (last < static_cast<uint64_t>(gg.nhc) * (hc_size / B) || total > length_bound(dtype, gg) || total > available_words) {
+        return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "header does not describe a stream that fits the given words");
+    }
+    *words = static_cast<uint32_t>(total);
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_offloader_submit_decompress(ndzip_hip_offloader *o, int slot, const uint32_t *extent, const void *stream,
+        uint32_t stream_length_words, void *data) {
+    offload_slot *s = nullptr;
+    if (int st = slot_of(o, slot, &s, true)) return st;
+    grid_geom gg;
+    if (int st = job_geometry(o, extent, &gg)) return st;
+    uint32_t words = 0;
+    if (int st = ndzip_hip_stream_words(o->dtype, o->dims, extent, stream, stream_length_words, &words)) return st;
+    const size_t wb = word_bytes(o->dtype);
+    const size_t out_bytes = static_cast<size_t>(num_elements(gg)) * wb;
+    if (out_bytes && !data) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null output");
+    if (words) HIP_TRY(hipMemcpyAsync(s->d_stream, stream, static_cast<size_t>(words) * wb, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipEventRecord(s->start, s->stream));
+    if (int st = ndzip_hip_decompressor_decompress(s->decomp, s->d_stream, s->d_array, o->dims, extent)) return st;
+    HIP_TRY(hipEventRecord(s->stop, s->stream));
+    if (out_bytes) HIP_TRY(hipMemcpyAsync(data, s->d_array, out_bytes, hipMemcpyDeviceToHost, s->stream));
+    s->job = 2;
+    s->host_out = data;
+    s->words = words;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, uint64_t *kernel_ns) {
+    offload_slot *s = nullptr;
+    if (int st = slot_of(o, slot, &s, false)) return st;
+    const int job = s->job;
+    s->job = 0;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (kernel_ns) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->start, s->stop));
+        *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+    }
+    if (job == 1) {
+        if (int st = ndzip_hip_compressor_check(s->comp)) return st;
+        const uint32_t len = *s->h_len;
+        const size_t wb = word_bytes(o->dtype);
+        if (static_cast<size_t>(len) * wb > o->stream_bytes) return fail(NDZIP_HIP_ERR_DEVICE_FAULT, "stream length exceeds bound");
+        if (len) {
+            HIP_TRY(hipMemcpyAsync(s->host_out, s->d_stream, static_cast<size_t>(len) * wb, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+        }
+        if (words) *words = len;
+    } else {
+        if (int st = ndzip_hip_decompressor_check(s->decomp)) return st;
+        if (words) *words = s->words;
+    }
+    return NDZIP_HIP_OK;
+}
+
 int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in, void *d_out,
         uint32_t *d_out_len, uint32_t n, void *hip_stream) {
     if (!valid_dtype(dtype) || !valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");

@@ -61,6 +61,14 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_decompressor_destroy",
     "ndzip_hip_offload_compress",
     "ndzip_hip_offload_decompress",
+    "ndzip_hip_offloader_create",
+    "ndzip_hip_offloader_destroy",
+    "ndzip_hip_host_alloc",
+    "ndzip_hip_host_free",
+    "ndzip_hip_offloader_submit_compress",
+    "ndzip_hip_offloader_submit_decompress",
+    "ndzip_hip_offloader_wait",
+    "ndzip_hip_stream_words",
     "ndzip_hip_debug_stage",
 )
 
@@ -106,6 +114,14 @@ def lib():
     L.ndzip_hip_decompressor_destroy.argtypes = [C.c_void_p]
     L.ndzip_hip_offload_compress.argtypes = [C.c_int, C.c_int, _U32P, C.c_void_p, C.c_void_p, _U32P, C.POINTER(C.c_uint64)]
     L.ndzip_hip_offload_decompress.argtypes = [C.c_int, C.c_int, _U32P, C.c_void_p, C.c_uint32, C.c_void_p, _U32P, C.POINTER(C.c_uint64)]
+    L.ndzip_hip_offloader_create.argtypes = [C.c_int, C.c_int, _U32P, C.c_int, C.POINTER(C.c_void_p)]
+    L.ndzip_hip_offloader_destroy.argtypes = [C.c_void_p]
+    L.ndzip_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.ndzip_hip_host_free.argtypes = [C.c_void_p]
+    L.ndzip_hip_offloader_submit_compress.argtypes = [C.c_void_p, C.c_int, _U32P, C.c_void_p, C.c_void_p]
+    L.ndzip_hip_offloader_submit_decompress.argtypes = [C.c_void_p, C.c_int, _U32P, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ndzip_hip_offloader_wait.argtypes = [C.c_void_p, C.c_int, _U32P, C.POINTER(C.c_uint64)]
+    L.ndzip_hip_stream_words.argtypes = [C.c_int, C.c_int, _U32P, C.c_void_p, C.c_uint64, _U32P]
     L.ndzip_hip_debug_stage.argtypes = [C.c_int, C.c_int, C.c_int, _U32P, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name != "ndzip_hip_last_error":
@@ -306,6 +322,91 @@ class HipOffloader:
                                                    out.ctypes.data, C.byref(n), C.byref(ns)))
         self.last_kernel_ns = ns.value
         return out, n.value
+
+
+def stream_words(dtype, extent, stream: np.ndarray) -> int:
+    """Length in words of the stream of an `extent` array that starts at stream[0], from its header alone."""
+    extent = tuple(int(x) for x in extent)
+    stream = np.ascontiguousarray(stream, dtype=word_dtype(dtype))
+    n = C.c_uint32(0)
+    _check(lib().ndzip_hip_stream_words(_dtype_code(dtype), len(extent), _ext(extent), stream.ctypes.data, stream.size, C.byref(n)))
+    return n.value
+
+
+class PinnedBuffer:
+    """Pinned host memory (ndzip_hip_host_alloc) exposed as a numpy array of `dtype`."""
+
+    def __init__(self, nbytes: int, dtype=np.uint8):
+        p = C.c_void_p()
+        _check(lib().ndzip_hip_host_alloc(max(1, int(nbytes)), C.byref(p)))
+        self._p = p
+        self.nbytes = int(nbytes)
+        raw = (C.c_uint8 * max(1, self.nbytes)).from_address(p.value)
+        self.array = np.frombuffer(raw, dtype=np.uint8)[: self.nbytes].view(dtype)
+
+    def close(self) -> None:
+        if self._p is not None:
+            self.array = None
+            lib().ndzip_hip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipPipelinedOffloader:
+    """Persistent host-pointer offloader with `slots` jobs in flight (ndzip_hip_offloader_*): the offloader<T>
+    OBJECT of offload.hh:8-34 for callers that stream many arrays, e.g. the chunk loop of src/compress/compress.cc:17-86."""
+
+    def __init__(self, dtype, max_extent, slots: int = 2):
+        self.np_dtype = np.dtype(dtype)
+        self.code = _dtype_code(dtype)
+        self.max_extent = tuple(int(x) for x in max_extent)
+        self.dims = len(self.max_extent)
+        if not 1 <= self.dims <= 3:
+            raise NdzipHipError(ERR_INVALID_ARGUMENT, "Invalid dimensionality")
+        self.slots = int(slots)
+        h = C.c_void_p()
+        _check(lib().ndzip_hip_offloader_create(self.code, self.dims, _ext(self.max_extent), self.slots, C.byref(h)))
+        self._h = h
+
+    def _extent(self, extent):
+        extent = tuple(int(x) for x in extent)
+        if len(extent) != self.dims:
+            raise NdzipHipError(ERR_DIMS_MISMATCH, "data dimensionality does not match compressor dimensionality")
+        return extent
+
+    def submit_compress(self, slot: int, data: np.ndarray, out_stream: np.ndarray, extent=None) -> None:
+        extent = self._extent(data.shape if extent is None else extent)
+        assert data.flags.c_contiguous and out_stream.flags.c_contiguous
+        _check(lib().ndzip_hip_offloader_submit_compress(self._h, slot, _ext(extent), data.ctypes.data, out_stream.ctypes.data))
+
+    def submit_decompress(self, slot: int, stream: np.ndarray, out_data: np.ndarray, extent=None) -> None:
+        extent = self._extent(out_data.shape if extent is None else extent)
+        assert stream.flags.c_contiguous and out_data.flags.c_contiguous
+        _check(lib().ndzip_hip_offloader_submit_decompress(self._h, slot, _ext(extent), stream.ctypes.data, stream.size,
+                                                           out_data.ctypes.data))
+
+    def wait(self, slot: int):
+        """-> (words, kernel_ns)"""
+        n = C.c_uint32(0)
+        ns = C.c_uint64(0)
+        _check(lib().ndzip_hip_offloader_wait(self._h, slot, C.byref(n), C.byref(ns)))
+        return n.value, ns.value
+
+    def close(self) -> None:
+        if self._h is not None:
+            lib().ndzip_hip_offloader_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def make_hip_compressor(dtype, requirements, stream: int = 0) -> HipCompressor:
