@@ -16,14 +16,15 @@ using tile_desc = unsigned long long;
 // line (see max_ticket_classes in codec_launch.inl).  Sizes in tile_desc units.
 constexpr unsigned max_ticket_classes = 16;
 constexpr unsigned ticket_stride_words = 32;  // uint32 words between the counters of consecutive classes
-constexpr unsigned scratch_extra_descs = 16 + max_ticket_classes * ticket_stride_words / 2;
+constexpr unsigned scratch_extra_descs = 16 + (max_ticket_classes + 1) * ticket_stride_words / 2;  // + the 'workgroups done' line
 
 struct compress_args {
     const void *in;        // device, value_type[num_elements]
     grid_geom gg;
     uint32_t *header;      // device, NHC uint32 entries (+1 pad entry for 64-bit streams with odd NHC)
     void *body;            // device, first body word (= stream + header words for a contiguous stream)
-    tile_desc *desc;       // device scratch, >= num_tiles + scratch_extra_descs entries, zeroed by the launcher on `stream`
+    tile_desc *desc;       // device scratch, >= num_tiles + scratch_extra_descs entries, zeroed ONCE by its owner
+    uint32_t epoch;        // launch counter of that scratch, 1 .. 2^30-1, different for every launch on it
     uint32_t *out_len;     // device scalar or nullptr
     uint32_t len_extra;    // header words + border words, added to the body length for *out_len
     uint32_t *err;         // device error word (sticky)

@@ -45,11 +45,26 @@ struct tile_cfg {
     static constexpr bool lookback_before_prefetch = false;
 #endif
     static constexpr uint32_t xchg_bytes = 32;  // per hypercube: 2 x uint32 + 2 x W
-    static constexpr uint32_t smem_bytes = K * L::cube_bytes + L::zero_bytes + K * xchg_bytes + 32;
+    // bytes between the staging regions of a tile's hypercubes: = 128 mod 256, see stage_pair_regs
+    static constexpr uint32_t cube_stride = L::cube_bytes + (K > 1 ? 128 : 0);
+    static constexpr uint32_t smem_bytes = K * cube_stride + L::zero_bytes + K * xchg_bytes + 32;
 };
 
-constexpr unsigned long long st_aggregate = 1ull << 32;
-constexpr unsigned long long st_inclusive = 2ull << 32;
+// Descriptor = (status << 32) | value with status = (epoch << 2) | state.  The epoch is a per-handle launch counter: a
+// descriptor left behind by an earlier launch has another epoch and reads as "not published", so the scratch needs no
+// clearing between launches (a 130 KiB memset node in front of every compress call cost ~4 us of a 200 us launch, and
+// 10 % of a 16 Mi-element one).  States: 0 unpublished, 1 aggregate, 2 inclusive prefix, 3 lane outside the window.
+struct desc_ref {
+    tile_desc *p;
+    uint32_t epoch;
+};
+NDZIP_DEV tile_desc desc_tag(uint32_t epoch, uint32_t state) {
+    return static_cast<tile_desc>((epoch << 2) | state) << 32;
+}
+NDZIP_DEV uint32_t desc_state(tile_desc d, uint32_t epoch) {
+    const uint32_t status = static_cast<uint32_t>(d >> 32);
+    return (status >> 2) == epoch ? (status & 3u) : 0u;
+}
 // Look-back window: how many predecessor descriptors one hop reads (one per lane).  Every descriptor read is an
 // uncached 8-byte agent-scope load, i.e. its own fabric transaction: measured on 512^3 f32, 256 per hop costs 45 us
 // more kernel time than 64 per hop, 1024 per hop 170 us more (profiles/) -- narrow windows win.
@@ -57,7 +72,6 @@ constexpr unsigned long long st_inclusive = 2ull << 32;
 #define NDZIP_LOOKBACK_LANES 64
 #endif
 constexpr int lookback_lanes = NDZIP_LOOKBACK_LANES;
-constexpr unsigned long long st_skip = 3ull << 32;  // lanes outside the window
 constexpr uint32_t spin_limit = 1u << 20;
 
 NDZIP_DEV tile_desc desc_load(const tile_desc *p) {
@@ -65,6 +79,17 @@ NDZIP_DEV tile_desc desc_load(const tile_desc *p) {
 }
 NDZIP_DEV void desc_store(tile_desc *p, tile_desc v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// tickets[class * ticket_stride_words] = next ticket of the class; tickets[max_ticket_classes * ticket_stride_words] =
+// number of workgroups that have drawn their last ticket
+NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid) {
+    if (tid != 0) return;
+    uint32_t *done = tickets + max_ticket_classes * ticket_stride_words;
+    if (atomicAdd(done, 1u) == gridDim.x - 1) {
+        for (uint32_t c = 0; c < num_classes; ++c) tickets[c * ticket_stride_words] = 0;
+        *done = 0;
+    }
 }
 
 NDZIP_DEV uint32_t wave_sum(uint32_t v) {
@@ -82,8 +107,8 @@ NDZIP_DEV uint32_t wave_sum(uint32_t v) {
 // inside the caller's buffer.  While a predecessor is missing only ONE lane polls ONE descriptor (with s_sleep):
 // window-wide polling by a thousand workgroups would eat the memory system (MI355X guide, "polling-cost").
 
-NDZIP_DEV void publish_aggregate(tile_desc *desc, uint32_t tile, uint32_t aggregate) {
-    desc_store(desc + tile, (tile == 0 ? st_inclusive : st_aggregate) | aggregate);
+NDZIP_DEV void publish_aggregate(desc_ref desc, uint32_t tile, uint32_t aggregate) {
+    desc_store(desc.p + tile, desc_tag(desc.epoch, tile == 0 ? 2u : 1u) | aggregate);
 }
 
 // Phase stagger: all workgroups of a launch start in the same phase, and the ordered write-out keeps them within
@@ -108,16 +133,16 @@ struct lookback_windows {
     tile_desc d[lookback_prefetch];
 };
 
-NDZIP_DEV void lookback_issue(const tile_desc *desc, uint32_t tile, int lane, lookback_windows &w) {
+NDZIP_DEV void lookback_issue(desc_ref desc, uint32_t tile, int lane, lookback_windows &w) {
 #pragma unroll
     for (int j = 0; j < lookback_prefetch; ++j) {
         const long long idx = static_cast<long long>(tile) - 1 - lane - j * lookback_lanes;
-        w.d[j] = lane >= lookback_lanes ? st_skip : idx >= 0 ? desc_load(desc + idx) : st_inclusive;
+        w.d[j] = lane >= lookback_lanes ? desc_tag(desc.epoch, 3u) : idx >= 0 ? desc_load(desc.p + idx) : desc_tag(desc.epoch, 2u);
     }
 }
 
 template<bool Preloaded>
-NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane,
+NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane,
         const lookback_windows &pre, uint32_t *hop_count = nullptr, uint32_t *poll_count = nullptr) {
     if (tile == 0) return 0;
     if constexpr (Preloaded) {
@@ -130,7 +155,7 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile,
 #pragma unroll
         for (int j = 0; j < lookback_prefetch; ++j) {
             const tile_desc d = pre.d[j];
-            const uint32_t status = static_cast<uint32_t>(d >> 32);
+            const uint32_t status = desc_state(d, desc.epoch);
             const unsigned long long invalid = __ballot(status == 0);
             const unsigned long long inclusive = __ballot(status == 2);
             if (complete && !done) {
@@ -151,7 +176,7 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile,
             }
         }
         if (done) {
-            if (lane == 0) desc_store(desc + tile, st_inclusive | (sum + aggregate));
+            if (lane == 0) desc_store(desc.p + tile, desc_tag(desc.epoch, 2u) | (sum + aggregate));
             return sum;
         }
     }
@@ -175,10 +200,10 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile,
         for (;;) {
             if (!use_preloaded) {
                 const long long idx = base - lane;
-                d = lane >= lookback_lanes ? st_skip : idx >= 0 ? desc_load(desc + idx) : st_inclusive;
+                d = lane >= lookback_lanes ? desc_tag(desc.epoch, 3u) : idx >= 0 ? desc_load(desc.p + idx) : desc_tag(desc.epoch, 2u);
             }
             use_preloaded = false;
-            const uint32_t status = static_cast<uint32_t>(d >> 32);
+            const uint32_t status = desc_state(d, desc.epoch);
             const unsigned long long invalid = __ballot(status == 0);
             const unsigned long long inclusive = __ballot(status == 2);
             found = inclusive != 0;
@@ -194,8 +219,8 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile,
             if (poll_count) ++*poll_count;
             // the nearest missing predecessor: one lane polls it, then the window is read again
             if (lane == 0) {
-                const tile_desc *p = desc + (base - wait_pos);
-                while (static_cast<uint32_t>(desc_load(p) >> 32) == 0 && spins < spin_limit) {
+                const tile_desc *p = desc.p + (base - wait_pos);
+                while (desc_state(desc_load(p), desc.epoch) == 0 && spins < spin_limit) {
                     __builtin_amdgcn_s_sleep(8);
                     ++spins;
                 }
@@ -215,11 +240,11 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(tile_desc *desc, uint32_t tile,
         ++hop;
     }
     if (timed_out && lane == 0) atomicOr(err, 1u);
-    if (lane == 0) desc_store(desc + tile, st_inclusive | (exclusive + aggregate));
+    if (lane == 0) desc_store(desc.p + tile, desc_tag(desc.epoch, 2u) | (exclusive + aggregate));
     return exclusive;
 }
 
-NDZIP_DEV uint32_t resolve_exclusive_prefix(tile_desc *desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane) {
+NDZIP_DEV uint32_t resolve_exclusive_prefix(desc_ref desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane) {
     lookback_windows none{};
     return resolve_exclusive_prefix_impl<false>(desc, tile, aggregate, err, lane, none);
 }
@@ -280,8 +305,9 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (tile_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
-        typename word_of<T>::type *__restrict__ body, tile_desc *desc, uint32_t *tickets, const uint32_t num_classes,
-        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags) {
+        typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags, const uint32_t epoch) {
+    const desc_ref desc{desc_base, epoch};
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -294,8 +320,8 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
     const int tid = static_cast<int>(threadIdx.x);
     const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
     const int lane = tid & 63, wave = tid >> 6;
-    char *cube = smem + grp * L::cube_bytes;        // staging of this group's hypercube
-    char *zero_region = smem + K * L::cube_bytes;
+    char *cube = smem + grp * C::cube_stride;       // staging of this group's hypercube
+    char *zero_region = smem + K * C::cube_stride;
     char *zero = zero_region + L::template zero_offset<Dims>();
     uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);              // the K encoded runs, back to back
@@ -409,10 +435,13 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
         NDZIP_PHASE(7)  // final barrier
         tile = next_tile;
     }
+    // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
+    // visible); the descriptors need no clearing (epoch).
+    release_tickets(tickets, num_classes, tid);
 #undef NDZIP_PHASE
 #ifdef NDZIP_EXP_PHASE_TIMING
     if (timing && tid == 0) {
-        unsigned long long *acc = desc + ntiles;
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(tickets) - 16;
 #pragma unroll
         for (int i = 0; i < 12; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
         atomicAdd(acc + 15, 1ull);
@@ -441,11 +470,14 @@ struct db_cfg {
 #endif
 };
 
-template<typename T, int Dims, bool Aligned>
+// Paired: the two hypercubes of every tile are neighbours along x (3D, 32-bit, even hypercube count along x, aligned
+// rows): the tile is fetched as 256 rows of 128 bytes (load_pair_regs) instead of 2 x 256 rows of 64 bytes.
+template<typename T, int Dims, bool Aligned, bool Paired = false>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (db_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
-        typename word_of<T>::type *__restrict__ body, tile_desc *desc, uint32_t *tickets, const uint32_t num_classes,
-        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags) {
+        typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags, const uint32_t epoch) {
+    const desc_ref desc{desc_base, epoch};
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -463,9 +495,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     const int tid = static_cast<int>(threadIdx.x);
     const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
     const int lane = tid & 63, wave = tid >> 6;
-    char *cube = smem + grp * L::cube_bytes;                              // staging of this group's hypercube
+    char *cube = smem + grp * C::cube_stride;                             // staging of this group's hypercube
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);             // later: the K encoded runs, back to back
-    char *zero_region = smem + K * L::cube_bytes;
+    char *zero_region = smem + K * C::cube_stride;
     char *zero = zero_region + L::template zero_offset<Dims>();
     uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
 
@@ -493,8 +525,12 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
 #else
 #define NDZIP_PHASE(i)
 #endif
+    static_assert(!Paired || (Dims == 3 && sizeof(W) == 4 && K == 2 && Aligned), "paired loads: 3D, 32-bit, aligned rows");
     input_regs<W, Aligned> pre;
-    {
+    if constexpr (Paired) {
+        const uint32_t first_tile = tile < ntiles ? tile : ntiles - 1;
+        load_pair_regs<>(in, gg, hc_origin<Dims>(gg, first_tile * K), tid, pre);
+    } else {
         uint32_t first_hc = tile * K + grp;
         if (first_hc >= gg.nhc) first_hc = gg.nhc - 1;
         load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, first_hc), t, pre);
@@ -519,18 +555,26 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (have_cur) {
             uint32_t next_ticket = 0;
             if (tid == 0) next_ticket = atomicAdd(ticket_counter, 1u);
-            if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
+            if constexpr (Paired) {
+                stage_pair_regs(pre, smem, C::cube_stride, tid);  // (an even hypercube count: both cubes of a tile exist)
+            } else {
+                if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
+            }
             if (tid == 0) misc[NW + 1] = next_ticket;
         }
         NDZIP_PHASE(0)  // ticket + wait prefetch + stage
         __syncthreads();  // B1: cube staged, next ticket known
         const uint32_t next_tile = have_cur ? misc[NW + 1] * num_classes + cls : tile;
         __builtin_amdgcn_sched_barrier(0);
-        uint32_t next_hc = next_tile * K + grp;
-        if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
+        uint32_t next_hc = Paired ? next_tile * K : next_tile * K + grp;
+        if (next_hc >= gg.nhc) next_hc = Paired ? gg.nhc - K : gg.nhc - 1;
         const uint64_t next_origin = hc_origin<Dims>(gg, next_hc);
         // early part of the next tile's prefetch (a whole iteration ahead of its use)
-        load_hypercube_regs<T, Dims, Aligned, 0, early_vectors>(in, gg, next_origin, t, pre);
+        if constexpr (Paired) {
+            load_pair_regs<0, early_vectors>(in, gg, next_origin, tid, pre);
+        } else {
+            load_hypercube_regs<T, Dims, Aligned, 0, early_vectors>(in, gg, next_origin, t, pre);
+        }
         __builtin_amdgcn_sched_barrier(0);
         W r[vals_per_thread];
         uint32_t head = 0, count = 0, incl = 0;
@@ -563,7 +607,11 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
         // live around the whole loop.
         __builtin_amdgcn_sched_barrier(0);
-        load_hypercube_regs<T, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
+        if constexpr (Paired) {
+            load_pair_regs<1, early_vectors>(in, gg, next_origin, tid, pre);
+        } else {
+            load_hypercube_regs<T, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
+        }
         __builtin_amdgcn_sched_barrier(0);
         NDZIP_PHASE(7)  // late prefetch issue
         if (have_prev) {
@@ -627,10 +675,13 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         prev_hc = hc;
         tile = next_tile;
     }
+    // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
+    // visible); the descriptors need no clearing (epoch).
+    release_tickets(tickets, num_classes, tid);
 #undef NDZIP_PHASE
 #ifdef NDZIP_EXP_PHASE_TIMING
     if (timing && tid == 0) {
-        unsigned long long *acc = desc + ntiles;
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(tickets) - 16;
 #pragma unroll
         for (int i = 0; i < 12; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
         atomicAdd(acc + 15, 1ull);
@@ -651,8 +702,8 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
 
     const int tid = static_cast<int>(threadIdx.x);
     const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
-    char *cube = smem + grp * L::cube_bytes;
-    uint32_t *xchg = reinterpret_cast<uint32_t *>(smem + K * L::cube_bytes + L::zero_bytes) + grp * (C::xchg_bytes / 4);
+    char *cube = smem + grp * C::cube_stride;
+    uint32_t *xchg = reinterpret_cast<uint32_t *>(smem + K * C::cube_stride + L::zero_bytes) + grp * (C::xchg_bytes / 4);
 
     const uint32_t hc = blockIdx.x * K + grp;
     const bool active = hc < gg.nhc;
@@ -764,14 +815,23 @@ hipError_t launch_compress_profile(const compress_args &a) {
     constexpr bool use_db = sizeof(T) == 4;
     constexpr uint32_t smem_bytes = C::smem_bytes;
     void (*kernel)(const W *, const grid_geom, uint32_t *, W *, tile_desc *, uint32_t *, const uint32_t, uint32_t *, uint32_t, uint32_t *,
-            const uint32_t);
+            const uint32_t, const uint32_t);
+    bool paired = false;
     if constexpr (use_db) {
-        kernel = compress_kernel_db<T, Dims, Aligned>;
+        if constexpr (Dims == 3 && Aligned) {
+            // tiles of two x-neighbours: needs an even hypercube count along x (then every tile 2m, 2m+1 is such a pair)
+            static const bool no_paired = getenv("NDZIP_HIP_NO_PAIRED") != nullptr;  // experiments only
+            paired = a.gg.g[2] % 2 == 0 && !no_paired;
+            kernel = paired ? compress_kernel_db<T, Dims, Aligned, true> : compress_kernel_db<T, Dims, Aligned, false>;
+        } else {
+            kernel = compress_kernel_db<T, Dims, Aligned>;
+        }
     } else {
         kernel = compress_kernel<T, Dims, Aligned>;
     }
     // persistent grid, fully resident: bounded by the occupancy query and by what the LDS alone admits
-    static int blocks_per_cu = 0;
+    static int blocks_per_cu_of[2] = {0, 0};
+    int &blocks_per_cu = blocks_per_cu_of[paired ? 1 : 0];
     if (blocks_per_cu == 0) {
         int api = 0;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -787,16 +847,20 @@ hipError_t launch_compress_profile(const compress_args &a) {
     static const int exp_bpc = getenv("NDZIP_HIP_BPC") ? atoi(getenv("NDZIP_HIP_BPC")) : 0;
     uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(exp_bpc > 0 && exp_bpc < blocks_per_cu ? exp_bpc : blocks_per_cu);
     if (grid > ntiles) grid = ntiles;
-    // scratch layout: [ntiles descriptors][16 x u64 experiment counters][max_ticket_classes ticket counters, one per 128 B]
-    hipError_t e = hipMemsetAsync(a.desc, 0, (static_cast<size_t>(ntiles) + scratch_extra_descs) * sizeof(tile_desc), a.stream);
-    if (e != hipSuccess) return e;
+    // scratch layout (fixed, whatever the extent): [16 x u64 experiment counters][max_ticket_classes ticket counters, one
+    // per 128 B][1 line: workgroups done][descriptors].  Nothing is cleared here: descriptors carry the launch epoch, the
+    // kernel zeroes the ticket counters on its way out (the owner of the scratch zeroes everything once).
+    if (exp_flags & 16u) {
+        hipError_t e = hipMemsetAsync(a.desc, 0, 16 * sizeof(tile_desc), a.stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg,
-            a.header, static_cast<W *>(a.body), a.desc, reinterpret_cast<uint32_t *>(a.desc + ntiles + 16),
-            grid >= max_ticket_classes ? max_ticket_classes : 1u, a.out_len, a.len_extra, a.err, exp_flags);
+            a.header, static_cast<W *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16),
+            grid >= max_ticket_classes ? max_ticket_classes : 1u, a.out_len, a.len_extra, a.err, exp_flags, a.epoch);
     if (exp_flags & 16u) {  // experiments only: dump the per-phase cycle totals of this launch
         unsigned long long acc[16];
         (void) hipStreamSynchronize(a.stream);
-        (void) hipMemcpy(acc, a.desc + ntiles, sizeof acc, hipMemcpyDeviceToHost);
+        (void) hipMemcpy(acc, a.desc, sizeof acc, hipMemcpyDeviceToHost);
         static int dumps = 0;
         if (dumps++ % 8 == 4) {
             const double n = static_cast<double>(acc[15] ? acc[15] : 1) * ((ntiles + grid - 1) / grid);
