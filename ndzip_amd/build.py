@@ -39,7 +39,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+            jobs.append([HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -47,6 +47,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if "-c" in cmd:  # keep the per-kernel register / scratch / occupancy remarks next to the object (kernel_resources())
+            with open(cmd[cmd.index("-o") + 1] + ".resources.txt", "w") as f:
+                f.write(r.stderr)
         return r
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
@@ -55,6 +58,34 @@ def build(force: bool = False, verbose: bool = False) -> str:
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs])
     build_cli(force=force, verbose=verbose)
     return OUT
+
+
+def kernel_resources() -> dict:
+    """{demangled-ish kernel name: {"vgprs", "scratch", "occupancy", "sgpr_spill"}} of the last build of every translation unit
+    (hipcc -Rpass-analysis=kernel-resource-usage).  A compress kernel with scratch is a performance bug: a scratch reload is a
+    vector-memory load and waits for every prefetch load issued before it."""
+    import re
+
+    out = {}
+    for src in SOURCES:
+        path = os.path.join(OBJDIR, src.replace(".hip", ".o")) + ".resources.txt"
+        if not os.path.exists(path):
+            continue
+        name = None
+        for line in open(path):
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                out[name] = {}
+                continue
+            if name is None:
+                continue
+            for key, pat in (("vgprs", r"\bVGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                             ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"), ("sgpr_spill", r"SGPRs Spill: (\d+)")):
+                m = re.search(pat, line)
+                if m:
+                    out[name][key] = int(m.group(1))
+    return out
 
 
 CLI_SRC = os.path.join(HERE, "cli", "ndzip_hip_cli.cc")

@@ -294,9 +294,21 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
     if (static_cast<uint32_t>(tid) < n - done) dst[done + tid] = src[done + tid];
 }
 
+// Ablation switches (tools/ablate.sh: NDZIP_HIP_EXP bit 0 no look-back, 1 no copy-out, 2 no plane writes, 4 phase timers,
+// bits 8.. start stagger) exist only in builds with -DNDZIP_EXP_ABLATION (or the phase timers' -DNDZIP_EXP_PHASE_TIMING):
+// as a run-time argument they cost the production kernel an SGPR and, at its register limit, a spilled pointer.
+#if defined(NDZIP_EXP_ABLATION) || defined(NDZIP_EXP_PHASE_TIMING)
+#define NDZIP_EXP_FLAGS(arg) const uint32_t exp_flags = (arg);
+#else
+#define NDZIP_EXP_FLAGS(arg) constexpr uint32_t exp_flags = 0u; (void) (arg);
+#endif
+
 // Tiles are handed out dynamically: `num_classes` ticket counters (class = blockIdx % num_classes, ticket n of class c
 // is tile n * num_classes + c), so tile order == start order, a tile's predecessors were all started before it, and
 // the look-back never depends on co-residency, dispatch order or placement.
+// One tile per ticket: handing a workgroup several CONSECUTIVE tiles (so that only the first needs the look-back) was
+// tried and serialises the grid -- the first tile of ticket q then waits for the LAST tile of ticket q-1, which its owner
+// reaches iterations later (2 tiles per ticket: 0.215 vs 0.201 ms; 4: 32 ms of bounded spinning).
 // Several counters, EACH IN ITS OWN CACHE LINE: returning atomics on one line serialise in its L2 channel at ~80-90 per
 // microsecond in total -- no matter how many words of the line they target -- and a 512^3 grid wants ~150 tickets per
 // microsecond.  With 16 counters packed into one line the ticket rate capped the whole kernel (tools/membench2.hip:
@@ -306,8 +318,9 @@ template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (tile_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
         typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
-        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags, const uint32_t epoch) {
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags_arg, const uint32_t epoch) {
     const desc_ref desc{desc_base, epoch};
+    NDZIP_EXP_FLAGS(exp_flags_arg)
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -476,8 +489,9 @@ template<typename T, int Dims, bool Aligned, bool Paired = false>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (db_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
         typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
-        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags, const uint32_t epoch) {
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags_arg, const uint32_t epoch) {
     const desc_ref desc{desc_base, epoch};
+    NDZIP_EXP_FLAGS(exp_flags_arg)
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;

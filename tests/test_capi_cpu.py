@@ -87,3 +87,24 @@ def test_product_package_never_touches_the_oracle():
                 text = open(os.path.join(base, f), errors="ignore").read()
                 for needle in ("import oracle", "from oracle", "libndzip_oracle", "ndzip_oracle_", "ndzip_ref_", "oracle/"):
                     assert needle not in text, f"{f} references the oracle ({needle})"
+
+
+def test_compress_and_decompress_kernels_do_not_spill():
+    """Register budget of the hot kernels (hipcc's resource remarks of the in-tree build).  Scratch in a compress kernel is a
+    performance bug, not just slowness: a scratch reload is a vector-memory load, it retires in order behind every prefetch
+    load of the wavefront and so waits out a full HBM round trip."""
+    from ndzip_amd import build
+
+    build.build()
+    res = build.kernel_resources()
+    if not res:  # objects older than the resource capture: rebuild once
+        build.build(force=True)
+        res = build.kernel_resources()
+    hot = {k: v for k, v in res.items() if "compress_kernel" in k}  # compress_kernel, compress_kernel_db, decompress_kernel
+    assert len(hot) >= 24, sorted(res)
+    for name, r in hot.items():
+        assert r["scratch"] == 0, f"{name} spills {r['scratch']} bytes per lane"
+    f32_db = [v for k, v in hot.items() if "compress_kernel_dbIf" in k]
+    assert f32_db and all(r["occupancy"] >= 3 for r in f32_db)       # 3 workgroups of 4 wavefronts per CU
+    dec = [v for k, v in hot.items() if "decompress_kernelIf" in k]
+    assert dec and all(r["occupancy"] >= 8 for r in dec)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# timing experiments on the GPU box (compress only):
+# timing experiments on the GPU box (compress only); needs a library built with NDZIP_EXTRA_FLAGS=-DNDZIP_EXP_ABLATION:
 #   NDZIP_HIP_EXP bit0 = no look-back (fake offsets), bit1 = no copy-out, bit2 = no plane writes
 #   NDZIP_HIP_BPC = cap on resident workgroups per CU
 run() { echo -n "EXP=$1 BPC=$2: "; NDZIP_HIP_EXP=$1 NDZIP_HIP_BPC=$2 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compress-only "${@:3}" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('compress_ms', d['roofline']['launch_ms'])"; }
