@@ -88,20 +88,25 @@ def kernel_resources() -> dict:
     return out
 
 
-CLI_SRC = os.path.join(HERE, "cli", "ndzip_hip_cli.cc")
+CLI_TOOLS = {  # binary next to the library it loads: source
+    os.path.join(HERE, "ndzip-hip"): os.path.join(HERE, "cli", "ndzip_hip_cli.cc"),
+    os.path.join(HERE, "ndzip-hip-benchmark"): os.path.join(HERE, "cli", "ndzip_hip_benchmark.cc"),
+}
 CLI_OUT = os.path.join(HERE, "ndzip-hip")
+BENCHMARK_OUT = os.path.join(HERE, "ndzip-hip-benchmark")
 
 
 def build_cli(force: bool = False, verbose: bool = False) -> str:
-    """The file-level tool (plain C++ over the C ABI, no HIP headers): ndzip_amd/ndzip-hip, next to the library it loads."""
-    if force or _stale(CLI_OUT, [CLI_SRC, OUT, os.path.join(HERE, "..", "include", "ndzip_hip.h")]):
-        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", CLI_OUT, CLI_SRC, "-L" + HERE, "-lndzip_hip",
-               "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"g++ failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    """The file-level tools (plain C++ over the C ABI, no HIP headers): ndzip_amd/ndzip-hip (the reference's `compress`) and
+    ndzip_amd/ndzip-hip-benchmark (the `ndzip-hip` rows of the reference's benchmark CSV)."""
+    for out, src in CLI_TOOLS.items():
+        if force or _stale(out, [src, OUT, os.path.join(HERE, "..", "include", "ndzip_hip.h")]):
+            cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", out, src, "-L" + HERE, "-lndzip_hip", "-Wl,-rpath,$ORIGIN"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"g++ failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
     return CLI_OUT
 
 

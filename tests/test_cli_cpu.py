@@ -66,3 +66,25 @@ def test_stream_words_splits_concatenated_streams(dtype):
         if oracle.num_hypercubes(shape):
             with pytest.raises(ndzip_amd.NdzipHipError):
                 ndzip_amd.stream_words(dtype, shape, streams[0][: len(streams[0]) - 1])
+
+
+def test_benchmark_tool_parses_the_reference_dataset_csv(tmp_path):
+    """src/benchmark/benchmark.cc:102-125: `name;float|double;n0 [n1 [n2]]`; malformed lines are fatal; header line is printed."""
+    ndzip_amd.hip.lib()
+    build.build_cli()
+    tool = build.BENCHMARK_OUT
+    bad = tmp_path / "bad.csv"
+    bad.write_text("a.bin;int;4096\n")
+    r = subprocess.run([tool, str(bad)], capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"Invalid line" in r.stderr
+    r = subprocess.run([tool], capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"csv-file" in r.stderr
+    r = subprocess.run([tool, "-a", "zfp", str(bad)], capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"unknown algorithm" in r.stderr
+    empty = tmp_path / "empty.csv"
+    empty.write_text("")
+    r = subprocess.run([tool, str(empty)], capture_output=True, timeout=120)
+    assert r.returncode == 0
+    assert r.stdout.decode().strip() == ("dataset;data type;dimensions;algorithm;tunable;number of threads;"
+                                         "compression times (microseconds);decompression times (microseconds);"
+                                         "uncompressed bytes;compressed bytes")

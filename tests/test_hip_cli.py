@@ -107,3 +107,31 @@ def test_pipelined_offloader_matches_oracle(hiplib, cuda_device, case):
     off.close()
     for b in ins + outs:
         b.close()
+
+
+def test_benchmark_tool_writes_the_reference_result_csv(hiplib, cuda_device, tmp_path):
+    """Column set and row format of src/benchmark/benchmark.cc:1332-1337,1487-1489, sizes against the oracle."""
+    sets = [("a.f32", np.float32, (70, 130)), ("b.f64", np.float64, (16, 40, 17)), ("c.f32", np.float32, (4096 * 3 + 5,))]
+    lines = []
+    want = {}
+    for name, dtype, shape in sets:
+        data = synth_numpy(shape, dtype, seed=11, noise_mask=0xFF)
+        data.tofile(tmp_path / name)
+        lines.append(f"{name};{'float' if dtype == np.float32 else 'double'};{' '.join(str(x) for x in shape)}")
+        want[name] = (data.nbytes, oracle.compress(data).nbytes, len(shape))
+    (tmp_path / "sets.csv").write_text("\n".join(lines) + "\n")
+    build.build_cli()
+    r = subprocess.run([build.BENCHMARK_OUT, "-r", "3", "-t", "1", str(tmp_path / "sets.csv")], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    rows = r.stdout.decode().strip().split("\n")
+    assert rows[0].split(";") == ["dataset", "data type", "dimensions", "algorithm", "tunable", "number of threads",
+                                  "compression times (microseconds)", "decompression times (microseconds)", "uncompressed bytes",
+                                  "compressed bytes"]
+    assert len(rows) == 1 + len(sets)
+    for row in rows[1:]:
+        c = row.split(";")
+        raw, comp, dims = want[c[0]]
+        assert c[1] in ("float", "double") and int(c[2]) == dims and c[3] == "ndzip-hip" and c[4] == "1" and c[5] == "1"
+        ct, dt = [int(x) for x in c[6].split(",")], [int(x) for x in c[7].split(",")]
+        assert len(ct) >= 3 and len(dt) >= 3 and all(x >= 0 for x in ct + dt)
+        assert int(c[8]) == raw and int(c[9]) == comp
