@@ -216,7 +216,7 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
                 wait_pos = __builtin_ctzll(invalid);
             }
             if (wait_pos < 0) break;
-            if (poll_count) ++*poll_count;
+            if (poll_count) *poll_count += 100;  // (experiments: x100 so that averages below 1 show)
             // the nearest missing predecessor: one lane polls it, then the window is read again
             if (lane == 0) {
                 const tile_desc *p = desc.p + (base - wait_pos);
@@ -397,6 +397,9 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
             if (g == grp) my_len = len_g;
             aggregate += len_g;
         }
+        // (measured, 2D f64 8192^2: ticket drawn at the top of the iteration and consumed before this store 0.254 vs
+        // 0.245 ms; aggregate + ticket from wavefront 1 and the look-back wavefront prefetching after its look-back 0.27;
+        // 128 descriptors per hop as 16-byte loads 0.266; fewer ticket classes slower)
         uint32_t next_ticket = 0;
         if (tid == 0) {
             publish_aggregate(desc, tile, aggregate);      // as early as possible: successors wait on this
@@ -421,8 +424,13 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
         }
         if (wave == 0) {
             // (exp_flags: timing experiments only, see tools/ablate.sh; 0 in production)
+#ifdef NDZIP_EXP_PHASE_TIMING
+            const uint32_t exclusive = (exp_flags & 1u) ? tile * static_cast<uint32_t>(K * P::max_hc_words)
+                                                        : resolve_exclusive_prefix_impl<false>(desc, tile, aggregate, err, lane, lookback_windows{}, &ticks[10], &ticks[11]);
+#else
             const uint32_t exclusive = (exp_flags & 1u) ? tile * static_cast<uint32_t>(K * P::max_hc_words)
                                                         : resolve_exclusive_prefix(desc, tile, aggregate, err, lane);
+#endif
             if (tid == 0) misc[NW] = exclusive;
         }
         NDZIP_PHASE(4)  // look-back (wave 0)
@@ -818,6 +826,11 @@ __global__ void debug_transpose_kernel(const uint32_t *in, uint32_t *out, uint32
     for (int j = 0; j < 32; ++j) out[i * 32 + j] = x[j];
 }
 
+template<typename T>
+constexpr uint32_t ticket_classes_for() {
+    return max_ticket_classes;
+}
+
 template<typename T, int Dims, bool Aligned>
 hipError_t launch_compress_profile(const compress_args &a) {
     using C = tile_cfg<T, Dims>;
@@ -868,9 +881,12 @@ hipError_t launch_compress_profile(const compress_args &a) {
         hipError_t e = hipMemsetAsync(a.desc, 0, 16 * sizeof(tile_desc), a.stream);
         if (e != hipSuccess) return e;
     }
+    static const uint32_t exp_classes = getenv("NDZIP_HIP_CLASSES") ? static_cast<uint32_t>(atoi(getenv("NDZIP_HIP_CLASSES"))) : 0u;  // experiments
+    uint32_t num_classes = exp_classes >= 1 && exp_classes <= max_ticket_classes ? exp_classes : ticket_classes_for<T>();
+    if (grid < num_classes) num_classes = 1;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg,
             a.header, static_cast<W *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16),
-            grid >= max_ticket_classes ? max_ticket_classes : 1u, a.out_len, a.len_extra, a.err, exp_flags, a.epoch);
+            num_classes, a.out_len, a.len_extra, a.err, exp_flags, a.epoch);
     if (exp_flags & 16u) {  // experiments only: dump the per-phase cycle totals of this launch
         unsigned long long acc[16];
         (void) hipStreamSynchronize(a.stream);
