@@ -692,12 +692,24 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
         if (lane == 63) xchg[wave] = incl;
         __syncthreads();
         const uint32_t base = P::head_words + (wave ? xchg[0] : 0u) + incl - cnt;
+        // all 32 planes present at a 16-byte aligned position: eight 16-byte reads instead of 32 word reads at a lane
+        // stride of 32 words (32-way bank conflicts when whole wavefronts are that dense: incompressible data)
+        if (head == 0xffffffffu && ((reinterpret_cast<uintptr_t>(in32 + base) & 15u) == 0)) {
+            const char *src = reinterpret_cast<const char *>(in32 + base);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            // planes above i that are present = set head bits among the top i bits
-            const uint32_t above = i == 0 ? 0u : (head & ~(0xffffffffu >> i));
-            const uint32_t w = in32[base + static_cast<uint32_t>(__builtin_popcount(above))];
-            r[i] = ((head >> (31 - i)) & 1u) ? w : 0u;
+            for (int i = 0; i < 8; ++i) {
+                const vec16 v = lds_read16(src + 16 * i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[4 * i + j] = v.w[j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                // planes above i that are present = set head bits among the top i bits
+                const uint32_t above = i == 0 ? 0u : (head & ~(0xffffffffu >> i));
+                const uint32_t w = in32[base + static_cast<uint32_t>(__builtin_popcount(above))];
+                r[i] = ((head >> (31 - i)) & 1u) ? w : 0u;
+            }
         }
         if constexpr (ComplementInPlaneDomain) {
 #pragma unroll

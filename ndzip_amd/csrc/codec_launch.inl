@@ -642,9 +642,25 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
                 uint32_t *run = tile_run + prev_run_start;
                 uint32_t pos = P::head_words + prev_chunk_excl;
                 run[t] = prev_head;
+                // A chunk that keeps all 32 planes at a 16-byte aligned position goes out as eight 16-byte writes: when
+                // whole wavefronts are that dense (incompressible data) the word-by-word compaction below writes at a
+                // lane stride of 32 words, a 32-way bank conflict on each of its 32 instructions (random bits: compress
+                // 0.345 -> 0.29 ms for 512^3).
+                const bool dense = prev_head == 0xffffffffu && ((prev_run_start + pos) & 3u) == 0;
+                if (dense) {
+                    char *dst = reinterpret_cast<char *>(run + pos);
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    if (planes[i] != 0) run[pos++] = planes[i];
+                    for (int i = 0; i < 8; ++i) {
+                        vec16 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v.w[j] = planes[4 * i + j];
+                        lds_write16(dst + 16 * i, v);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        if (planes[i] != 0) run[pos++] = planes[i];
+                    }
                 }
             }
         }
