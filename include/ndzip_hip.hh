@@ -274,6 +274,84 @@ class hip_offloader final : public offloader<T> {
     dim_type _dims;
 };
 
+// Persistent, pipelined host-pointer offloader (ndzip_hip_offloader_*): device buffers, streams and codec handles are created
+// once for arrays up to `max_size`; `slots` jobs are in flight, so the H2D copy of one array, the kernels of the previous one
+// and the D2H copy of the one before overlap.  It IS an offloader<T> (compress / decompress run one job on slot 0 and wait),
+// and adds submit / wait for callers that keep several arrays in flight, e.g. the chunk loop of src/compress/compress.cc:34-45.
+template<typename T>
+class hip_pipelined_offloader final : public offloader<T> {
+  public:
+    using value_type = T;
+    using compressed_type = ndzip::compressed_type<T>;
+
+    hip_pipelined_offloader(const extent &max_size, int slots) : _dims(max_size.dimensions()), _slots(slots) {
+        hip_detail::check(ndzip_hip_offloader_create(hip_detail::dtype_of<T>(), _dims, max_size.begin(), slots, &_h));
+    }
+    ~hip_pipelined_offloader() override { ndzip_hip_offloader_destroy(_h); }
+    hip_pipelined_offloader(const hip_pipelined_offloader &) = delete;
+    hip_pipelined_offloader &operator=(const hip_pipelined_offloader &) = delete;
+
+    int slots() const { return _slots; }
+
+    // `data` / `stream` must stay valid until wait(slot); use hip_host_buffer for pinned memory
+    void submit_compress(int slot, const value_type *data, const extent &data_size, compressed_type *stream) {
+        check_dims(data_size);
+        hip_detail::check(ndzip_hip_offloader_submit_compress(_h, slot, data_size.begin(), data, stream));
+    }
+    void submit_decompress(int slot, const compressed_type *stream, index_type length, value_type *data, const extent &data_size) {
+        check_dims(data_size);
+        hip_detail::check(ndzip_hip_offloader_submit_decompress(_h, slot, data_size.begin(), stream, length, data));
+    }
+    // returns what the reference call returns: stream length in words / words consumed
+    index_type wait(int slot, kernel_duration *duration = nullptr) {
+        uint32_t words = 0;
+        uint64_t ns = 0;
+        hip_detail::check(ndzip_hip_offloader_wait(_h, slot, &words, duration ? &ns : nullptr));
+        if (duration) *duration = kernel_duration{ns};
+        return words;
+    }
+
+  protected:
+    index_type do_compress(const value_type *data, const extent &data_size, compressed_type *stream, kernel_duration *duration) override {
+        submit_compress(0, data, data_size, stream);
+        return wait(0, duration);
+    }
+    index_type do_decompress(const compressed_type *stream, index_type length, value_type *data, const extent &data_size,
+            kernel_duration *duration) override {
+        submit_decompress(0, stream, length, data, data_size);
+        return wait(0, duration);
+    }
+
+  private:
+    void check_dims(const extent &e) const {
+        if (e.dimensions() != _dims) throw std::runtime_error("data dimensionality does not match compressor dimensionality");
+    }
+    dim_type _dims;
+    int _slots;
+    ndzip_hip_offloader *_h = nullptr;
+};
+
+// pinned host memory for the buffers of in-flight jobs (ndzip_hip_host_alloc)
+template<typename U>
+class hip_host_buffer {
+  public:
+    explicit hip_host_buffer(size_t count) : _count(count) {
+        void *p = nullptr;
+        hip_detail::check(ndzip_hip_host_alloc(count * sizeof(U), &p));
+        _p = static_cast<U *>(p);
+    }
+    ~hip_host_buffer() { ndzip_hip_host_free(_p); }
+    hip_host_buffer(const hip_host_buffer &) = delete;
+    hip_host_buffer &operator=(const hip_host_buffer &) = delete;
+    U *data() { return _p; }
+    const U *data() const { return _p; }
+    size_t size() const { return _count; }
+
+  private:
+    U *_p = nullptr;
+    size_t _count;
+};
+
 // factories, named after make_cuda_compressor / make_cuda_decompressor / make_cuda_offloader (cuda.hh:36-41, offload.hh:55-57)
 template<typename T>
 std::unique_ptr<hip_compressor<T>> make_hip_compressor(const compressor_requirements &req, void *hip_stream = nullptr) {
@@ -288,6 +366,11 @@ std::unique_ptr<hip_decompressor<T>> make_hip_decompressor(dim_type dims, void *
 template<typename T>
 std::unique_ptr<offloader<T>> make_hip_offloader(dim_type dimensions) {
     return std::make_unique<hip_offloader<T>>(dimensions);
+}
+
+template<typename T>
+std::unique_ptr<hip_pipelined_offloader<T>> make_hip_pipelined_offloader(const extent &max_size, int slots = 2) {
+    return std::make_unique<hip_pipelined_offloader<T>>(max_size, slots);
 }
 
 }  // namespace ndzip

@@ -3,6 +3,7 @@
 // like after switching back-ends.  Built with g++ and linked against libndzip_hip.so by tests/test_cpp_adaptor.py.
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <random>
 #include <vector>
 
@@ -33,6 +34,47 @@ int run(ndzip::dim_type dims, ndzip::index_type n) {
     return threw ? 0 : 4;
 }
 
+// several arrays in flight through the persistent offloader, pinned buffers; every stream must equal the one-shot offloader's
+template<typename T>
+int run_pipelined(ndzip::dim_type dims, ndzip::index_type n) {
+    const auto size = ndzip::extent::broadcast(dims, n);
+    const size_t count = ndzip::num_elements(size), bound = ndzip::hip_compressed_length_bound<T>(size);
+    constexpr int slots = 3, jobs = 7;
+    auto pipe = ndzip::make_hip_pipelined_offloader<T>(size, slots);
+    auto oneshot = ndzip::make_hip_offloader<T>(dims);
+    std::vector<std::unique_ptr<ndzip::hip_host_buffer<T>>> in;
+    std::vector<std::unique_ptr<ndzip::hip_host_buffer<ndzip::compressed_type<T>>>> out;
+    for (int s = 0; s < slots; ++s) {
+        in.emplace_back(new ndzip::hip_host_buffer<T>(count));
+        out.emplace_back(new ndzip::hip_host_buffer<ndzip::compressed_type<T>>(bound));
+    }
+    std::minstd_rand gen(7);
+    std::uniform_real_distribution<T> dist;
+    std::vector<std::vector<T>> inputs(jobs, std::vector<T>(count));
+    for (auto &v : inputs) for (auto &x : v) x = dist(gen);
+    std::vector<std::vector<ndzip::compressed_type<T>>> streams;
+    auto retire = [&](int j) {
+        const auto words = pipe->wait(j % slots);
+        streams.emplace_back(out[j % slots]->data(), out[j % slots]->data() + words);
+    };
+    for (int j = 0; j < jobs; ++j) {
+        if (j >= slots) retire(j - slots);
+        std::memcpy(in[j % slots]->data(), inputs[j].data(), count * sizeof(T));
+        pipe->submit_compress(j % slots, in[j % slots]->data(), size, out[j % slots]->data());
+    }
+    for (int j = jobs - slots; j < jobs; ++j) retire(j);
+    std::vector<ndzip::compressed_type<T>> ref(bound);
+    for (int j = 0; j < jobs; ++j) {
+        const auto words = oneshot->compress(inputs[j].data(), size, ref.data());
+        if (words != streams[j].size() || std::memcmp(ref.data(), streams[j].data(), words * sizeof(ref[0])) != 0) return 1;
+    }
+    // ... and it is an offloader<T>
+    ndzip::offloader<T> &as_offloader = *pipe;
+    std::vector<T> back(count);
+    if (as_offloader.decompress(streams[2].data(), static_cast<ndzip::index_type>(streams[2].size()), back.data(), size) != streams[2].size()) return 2;
+    return std::memcmp(back.data(), inputs[2].data(), count * sizeof(T)) != 0 ? 3 : 0;
+}
+
 int main() {
     int rc = 0;
     rc |= run<float>(1, 4096 * 4 - 1);
@@ -41,6 +83,8 @@ int main() {
     rc |= run<double>(1, 4096 * 4 - 1) << 12;
     rc |= run<double>(2, 64 * 4 - 1) << 16;
     rc |= run<double>(3, 16 * 4 - 1) << 20;
+    rc |= run_pipelined<float>(3, 16 * 4 - 1) << 24;
+    rc |= run_pipelined<double>(2, 64 * 3 + 5) << 26;
     std::printf(rc ? "FAILED 0x%x\n" : "adaptor round trips ok\n", rc);
     return rc != 0;
 }

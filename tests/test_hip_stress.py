@@ -60,3 +60,42 @@ def test_compress_under_background_load(hiplib, cuda_device, dtype, shape):
             assert n == len(want) and np.array_equal(got, want), f"iteration {it}"
     torch.cuda.synchronize()
     comp.check()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_concurrent_compressors_on_separate_streams(hiplib, cuda_device, dtype):
+    """Several persistent compress grids in flight at once (one handle + stream each, as the pipelined offloader does): none
+    of them can count on having the device to itself, so a grid's workgroups start whenever the others leave room.  Tickets are
+    drawn only by workgroups that are running, so every look-back waits on resident work -- the streams must all be exact.
+    The same handles are then reused with a smaller and a larger extent (descriptor epochs, ticket counters restored by the
+    previous launch)."""
+    import torch
+
+    import ndzip_amd
+
+    n_streams = 4
+    shapes = [(96, 128, 160), (48, 64, 80), (112, 128, 160)]
+    req = ndzip_amd.CompressorRequirements(*shapes)
+    wdt = torch.int32 if dtype == np.float32 else torch.int64
+    streams = [torch.cuda.Stream(device=cuda_device) for _ in range(n_streams)]
+    comps = [ndzip_amd.make_hip_compressor(dtype, req, s.cuda_stream) for s in streams]
+    for round_, shape in enumerate(shapes * 2):
+        datas = [_uneven_grid(shape, dtype, 10 * round_ + i) for i in range(n_streams)]
+        wants = [oracle.compress(d, num_threads=oracle.max_threads()) for d in datas]
+        d_ins = [torch.from_numpy(d).to(cuda_device) for d in datas]
+        bound = ndzip_amd.compressed_length_bound(dtype, shape)
+        outs = [torch.zeros(bound, dtype=wdt, device=cuda_device) for _ in range(n_streams)]
+        lens = [torch.zeros(1, dtype=torch.int32, device=cuda_device) for _ in range(n_streams)]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for i in range(n_streams):
+                with torch.cuda.stream(streams[i]):
+                    comps[i].compress(d_ins[i], shape, outs[i], lens[i])
+        torch.cuda.synchronize()
+        for i in range(n_streams):
+            comps[i].check()
+            n = int(lens[i].cpu().numpy().view(np.uint32)[0])
+            got = outs[i][:n].cpu().numpy().view(wants[i].dtype)
+            assert n == len(wants[i]) and np.array_equal(got, wants[i]), (round_, i)
+    for c in comps:
+        c.close()
