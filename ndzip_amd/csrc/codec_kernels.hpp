@@ -56,10 +56,10 @@ NDZIP_DEV int popcount_w(uint64_t v) { return __builtin_popcountll(v); }
 // four of these (see encode/decode below).
 // ---------------------------------------------------------------------------------------------------------
 
-template<int S, uint32_t M>
-NDZIP_DEV void swap_stage(uint32_t (&x)[32]) {
+template<int S, uint32_t M, int N = 32>
+NDZIP_DEV void swap_stage(uint32_t (&x)[N]) {
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
+    for (int r = 0; r < N; ++r) {
         if ((r & S) == 0) {
             const uint32_t a = x[r], b = x[r + S];
             x[r] = (a & ~M) | ((b >> S) & M);      // v_lshrrev + v_bfi

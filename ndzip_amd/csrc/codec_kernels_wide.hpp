@@ -1,19 +1,23 @@
-// ndzip_amd/csrc/codec_kernels_wide.hpp -- f64 ENCODE with 256 work-items per hypercube ("wide" mapping).
+// ndzip_amd/csrc/codec_kernels_wide.hpp -- ENCODE with 256 work-items per hypercube ("wide" mapping): a work-item owns 16
+// consecutive cube-local values, a chunk of B values spans B/16 lanes (2 for f32, 4 for f64).
 //
-// The 128-work-item mapping of codec_kernels.hpp gives an f64 work-item 32 values = 64 VGPRs of residuals and 64 VGPRs
-// of plane words: too much to keep an encoded tile in registers across an iteration, so the f64 compress kernel had to
-// write a tile out in the iteration that encoded it, with its look-back on the critical path.  Here a work-item owns 16
-// consecutive cube-local values; a 64-value chunk spans 4 lanes.  Per work-item that is 32 VGPRs of values, 32 VGPRs of
-// prefetch and -- after the transpose -- 32 VGPRs of plane words: exactly the register picture of the f32 kernel, so the
-// register-buffered deferred-write-out pipeline (compress_kernel_db) carries over.
+// Why: with the 128-work-item mapping of codec_kernels.hpp an f64 work-item carries 64 VGPRs of residuals and 64 VGPRs of
+// plane words -- too much to keep an encoded tile in registers across an iteration, so the f64 compress kernel had to write
+// a tile out in the iteration that encoded it, with its look-back on the critical path.  Here a work-item carries, per 16
+// values, sizeof(W)*4 VGPRs of values, the same of prefetch and -- after the transpose -- the same of plane words.  For
+// f64 that is exactly the register picture of the 128-lane f32 kernel, so its register-buffered deferred-write-out
+// pipeline carries over (2D f64 8192^2: 0.253 -> 0.210 ms; 3D f64 512^3: 0.479 -> 0.391 ms).  For f32 it halves the
+// registers and the tile (one hypercube, 16 KiB), i.e. twice the workgroups per CU and half the pipeline fill / drain.
 //
-// Bit transpose of a chunk (64 values x 64 bits) over its lane quad q = 0..3 (values 16q .. 16q+15):
-//   1. the two lanes of a pair (0,1) / (2,3) swap halves: the even lane ends up with the HIGH dwords of the pair's 32
-//      values, the odd lane with the LOW dwords (16 DPP moves each);
-//   2. one 32x32 transpose per lane (the f32 network).
-// Lane 0 then holds, for the planes 0..31 (bits 63..32), the dword that covers values 0..31 = the HIGH dword of the
-// 64-bit plane word; lane 2 the LOW dword of the same planes (values 32..63); lanes 1 / 3 the same for planes 32..63.
-// Each lane compacts its 32 dwords (32 conditional writes instead of the narrow mapping's 64).
+// Bit transpose of a chunk over its lanes:
+//   f64 (lane quad q = 0..3, values 16q .. 16q+15): the two lanes of a pair swap halves -- the even lane ends up with the
+//       HIGH dwords of the pair's 32 values, the odd lane with the LOW dwords (16 DPP moves) -- then one 32x32 transpose per
+//       lane.  Lane 0 holds, for planes 0..31 (bits 63..32), the dword covering values 0..31 = the HIGH dword of the 64-bit
+//       plane word; lane 2 the LOW dword of the same planes (values 32..63); lanes 1 / 3 likewise for planes 32..63.
+//   f32 (lane pair, values 16p .. 16p+15): the first stage of the 32x32 block-swap network (rows r <-> r+16) IS the
+//       exchange between the two lanes (16 DPP moves + 16 v_perm); the remaining four stages stay inside a lane.  The even
+//       lane ends up with planes 0..15, the odd lane with planes 16..31.
+// Each lane compacts its own plane words (32 resp. 16 conditional LDS writes).
 #pragma once
 
 #include "codec_kernels.hpp"
@@ -23,59 +27,71 @@ namespace wide {
 
 constexpr int threads = 256;  // work-items per hypercube
 constexpr int vals = 16;      // cube-local values [16 t, 16 t + 16) per work-item
-using W = uint64_t;
-constexpr uint32_t head_words = hc_size / 64;  // 64 chunk heads
 
+template<typename W>
 struct layout {
-    static constexpr uint32_t chunk_bytes = vals * sizeof(W) + 16;      // 144: the f32 mapping's lane stride
-    static constexpr uint32_t cube_bytes = threads * chunk_bytes;        // 36864
+    static constexpr uint32_t chunk_bytes = vals * sizeof(W) + 16;  // 144 (f64: 9 slots of 16 bytes) / 80 (f32: 5 slots)
+    static constexpr uint32_t cube_bytes = threads * chunk_bytes;    // 36864 / 20480
     static constexpr uint32_t zero_bytes = vals * sizeof(W) + 256;
-    // slot (mod 16) no in-cube lane of a 16-lane group touches in the neighbour reads: lane t sits in slot 9t mod 16;
-    // rows y-1 (lane t-1, 3D), (z-1,y-1) (t-17) and the 2D row above (t-4) leave slot 7 free where the border lanes are
-    static constexpr uint32_t zero_offset = 7 * 16;
-    NDZIP_DEV static constexpr uint32_t off(uint32_t k) { return k * 8u + (k >> 4) * 16u; }
+    // The 16-byte slot (mod 16) that no in-cube lane of a 16-lane group touches in the neighbour reads.  Lane t sits in slot
+    // 9t (f64) / 5t (f32) mod 16; the border lanes of rows y-1 (lane t-1, 3D), (z-1, y-1) (t-17) and of the 2D row above
+    // (t-4) would have used slot 7 (f64) / 11 (f32).
+    static constexpr uint32_t zero_offset = (sizeof(W) == 8 ? 7 : 11) * 16;
+    NDZIP_DEV static constexpr uint32_t off(uint32_t k) { return k * static_cast<uint32_t>(sizeof(W)) + (k >> 4) * 16u; }
 };
 
+template<typename W>
 struct input_regs {
-    static constexpr int NV = hc_size / 2 / threads;  // 8 vectors of two values
+    static constexpr int VE = 16 / sizeof(W);
+    static constexpr int NV = hc_size / VE / threads;  // 8 (f64) / 4 (f32) vectors
     vec16 v[NV];
 };
 
-// coalesced global loads: vector i of work-item t covers values (i*256 + t)*2; 512 values are whole rows / planes
-template<int Dims, bool Aligned, int Part = -1, int Split = 0>
-NDZIP_DEV void load_regs(const W *__restrict__ in, const grid_geom &gg, uint64_t origin, int t, input_regs &regs) {
+// coalesced global loads: vector i of work-item t covers values (i*256 + t)*VE; 256*VE values are whole rows / planes
+template<typename W, int Dims, bool Aligned, int Part = -1, int Split = 0>
+NDZIP_DEV void load_regs(const W *__restrict__ in, const grid_geom &gg, uint64_t origin, int t, input_regs<W> &regs) {
+    using R = input_regs<W>;
     constexpr int first = Part == 1 ? Split : 0;
-    constexpr int last = Part == 0 ? Split : input_regs::NV;
-    const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * 2u);
-    const uint64_t step = local_offset<Dims>(gg, threads * 2);
+    constexpr int last = Part == 0 ? Split : R::NV;
+    const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
+    const uint64_t step = local_offset<Dims>(gg, threads * R::VE);
 #pragma unroll
     for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned>(base + i * step);
 }
 
-NDZIP_DEV void stage_regs(const input_regs &regs, char *cube, int t) {
-    char *base = cube + layout::off(static_cast<uint32_t>(t) * 2u);
-    constexpr uint32_t step = layout::off(threads * 2);
+template<typename W>
+NDZIP_DEV void stage_regs(const input_regs<W> &regs, char *cube, int t) {
+    using R = input_regs<W>;
+    using L = layout<W>;
+    char *base = cube + L::off(static_cast<uint32_t>(t) * R::VE);
+    constexpr uint32_t step = L::off(threads * R::VE);
 #pragma unroll
-    for (int i = 0; i < input_regs::NV; ++i) {
+    for (int i = 0; i < R::NV; ++i) {
         vec16 r;
+        if constexpr (sizeof(W) == 4) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint64_t x = rotl1(static_cast<uint64_t>(regs.v[i].w[2 * j]) | (static_cast<uint64_t>(regs.v[i].w[2 * j + 1]) << 32));
-            r.w[2 * j] = static_cast<uint32_t>(x);
-            r.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
+            for (int j = 0; j < 4; ++j) r.w[j] = rotl1(regs.v[i].w[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint64_t x = rotl1(static_cast<uint64_t>(regs.v[i].w[2 * j]) | (static_cast<uint64_t>(regs.v[i].w[2 * j + 1]) << 32));
+                r.w[2 * j] = static_cast<uint32_t>(x);
+                r.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
+            }
         }
         lds_write16(base + i * step, r);
     }
 }
 
 // fused Lorenzo stencil out of LDS + complement_negative -> residuals r[16] of work-item t
-template<int Dims>
+template<typename W, int Dims>
 NDZIP_DEV void stencil(const char *cube, const char *zero, int t, W (&r)[vals]) {
+    using L = layout<W>;
     const uint32_t k0 = static_cast<uint32_t>(t) * vals;
-    const char *own = cube + layout::off(k0);
-    constexpr int Q = 4;  // values folded at a time (two 16-byte reads per row)
+    const char *own = cube + L::off(k0);
+    constexpr int Q = 32 / sizeof(W);  // values folded at a time (two 16-byte reads per row)
     if constexpr (Dims == 1) {
-        W prev = lds_read<W>(t > 0 ? cube + layout::off(k0 - 1) : zero, 0);
+        W prev = lds_read<W>(t > 0 ? cube + L::off(k0 - 1) : zero, 0);
 #pragma unroll
         for (int q = 0; q < vals / Q; ++q) {
             W o[Q];
@@ -89,9 +105,9 @@ NDZIP_DEV void stencil(const char *cube, const char *zero, int t, W (&r)[vals]) 
     } else if constexpr (Dims == 2) {
         // 64 x 64: work-item = quarter row; y = t / 4, quarter = t % 4
         const int y = t >> 2, qx = t & 3;
-        const char *up = y > 0 ? cube + layout::off(k0 - 64) : zero;
-        const W ol = lds_read<W>(qx ? cube + layout::off(k0 - 1) : zero, 0);
-        const W ul = lds_read<W>((qx && y > 0) ? cube + layout::off(k0 - 65) : zero, 0);
+        const char *up = y > 0 ? cube + L::off(k0 - 64) : zero;
+        const W ol = lds_read<W>(qx ? cube + L::off(k0 - 1) : zero, 0);
+        const W ul = lds_read<W>((qx && y > 0) ? cube + L::off(k0 - 65) : zero, 0);
         W left = ol - ul;
 #pragma unroll
         for (int q = 0; q < vals / Q; ++q) {
@@ -109,9 +125,9 @@ NDZIP_DEV void stencil(const char *cube, const char *zero, int t, W (&r)[vals]) 
     } else {
         // 16^3: work-item = row (z, y) = (t / 16, t % 16)
         const int z = t >> 4, y = t & 15;
-        const char *row_p = y > 0 ? cube + layout::off(k0 - 16) : zero;                  // (z, y-1)
-        const char *row_a1 = z > 0 ? cube + layout::off(k0 - 256) : zero;               // (z-1, y)
-        const char *row_p1 = (z > 0 && y > 0) ? cube + layout::off(k0 - 256 - 16) : zero;  // (z-1, y-1)
+        const char *row_p = y > 0 ? cube + L::off(k0 - 16) : zero;                    // (z, y-1)
+        const char *row_a1 = z > 0 ? cube + L::off(k0 - 256) : zero;                 // (z-1, y)
+        const char *row_p1 = (z > 0 && y > 0) ? cube + L::off(k0 - 256 - 16) : zero;  // (z-1, y-1)
         W carry = 0;
 #pragma unroll
         for (int q = 0; q < vals / Q; ++q) {
@@ -154,27 +170,124 @@ NDZIP_DEV uint32_t quad_or(uint32_t v) {
     return v;
 }
 
-// chunk head (64 bits, same on the 4 lanes of the chunk) of the residuals of work-item t
-NDZIP_DEV void chunk_head(const W (&r)[vals], uint32_t &head_hi, uint32_t &head_lo) {
-    W own = 0;
-#pragma unroll
-    for (int j = 0; j < vals; ++j) own |= r[j];
-    head_hi = quad_or(static_cast<uint32_t>(own >> 32));
-    head_lo = quad_or(static_cast<uint32_t>(own));
-}
+// What one work-item contributes to the encoded run of its chunk.
+template<typename W>
+struct coding;
 
-// residuals -> this lane's 32 plane dwords (see the file comment); q = t & 3
-NDZIP_DEV void transpose_chunk(const W (&r)[vals], int t, uint32_t (&planes)[32]) {
-    const bool odd = (t & 1) != 0;
+template<>
+struct coding<uint64_t> {
+    static constexpr int lanes_per_chunk = 4;
+    static constexpr int planes_per_lane = 32;
+    static constexpr uint32_t head_words = hc_size / 64;  // in 64-bit words
+    static constexpr uint32_t w32 = 2;                     // uint32 per stream word
+    // state a lane keeps for the deferred write-out
+    struct held {
+        uint32_t head_bits;  // head bits of this lane's planes, MSB = its first plane
+        uint32_t head_word;  // the uint32 of the chunk head this lane stores (lanes 0 / 1: high / low dword)
+        uint32_t slot;       // uint32 index of this lane's first plane word inside the run
+    };
+    // chunk head (same on the 4 lanes), count of its planes
+    NDZIP_DEV static uint32_t head_and_count(const uint64_t (&r)[vals], uint32_t &head_hi, uint32_t &head_lo) {
+        uint64_t own = 0;
 #pragma unroll
-    for (int j = 0; j < vals; ++j) {
-        const uint32_t hi = static_cast<uint32_t>(r[j] >> 32), lo = static_cast<uint32_t>(r[j]);
-        const uint32_t got = pair_swap(odd ? hi : lo);  // the even lane sends its low dwords, the odd lane its high ones
-        planes[j] = odd ? got : hi;                      // values 0..15 of the pair: the even lane's
-        planes[vals + j] = odd ? lo : got;               // values 16..31 of the pair: the odd lane's
+        for (int j = 0; j < vals; ++j) own |= r[j];
+        head_hi = quad_or(static_cast<uint32_t>(own >> 32));
+        head_lo = quad_or(static_cast<uint32_t>(own));
+        return static_cast<uint32_t>(__builtin_popcount(head_hi) + __builtin_popcount(head_lo));
     }
-    transpose32(planes);
-}
+    NDZIP_DEV static void transpose(const uint64_t (&r)[vals], int t, uint32_t (&planes)[planes_per_lane]) {
+        const bool odd = (t & 1) != 0;
+#pragma unroll
+        for (int j = 0; j < vals; ++j) {
+            const uint32_t hi = static_cast<uint32_t>(r[j] >> 32), lo = static_cast<uint32_t>(r[j]);
+            const uint32_t got = pair_swap(odd ? hi : lo);  // the even lane sends its low dwords, the odd lane its high ones
+            planes[j] = odd ? got : hi;                      // values 0..15 of the pair: the even lane's
+            planes[vals + j] = odd ? lo : got;               // values 16..31 of the pair: the odd lane's
+        }
+        transpose32(planes);
+    }
+    // chunk_pos: 64-bit word index of the chunk's first plane word inside the run
+    NDZIP_DEV static held hold(int t, uint32_t head_hi, uint32_t head_lo, uint32_t chunk_pos) {
+        const int q = t & 3;
+        held h;
+        h.head_bits = (q & 1) ? head_lo : head_hi;
+        h.head_word = (q & 1) ? head_lo : head_hi;
+        const uint32_t pos = chunk_pos + ((q & 1) ? static_cast<uint32_t>(__builtin_popcount(head_hi)) : 0u);
+        h.slot = 2 * pos + ((q & 2) ? 0u : 1u);  // lanes 0, 1: high dword of the plane word; lanes 2, 3: low dword
+        return h;
+    }
+    NDZIP_DEV static void write(const held &h, const uint32_t (&planes)[planes_per_lane], uint32_t *run32, int t) {
+        const int q = t & 3;
+        const uint32_t c = static_cast<uint32_t>(t) >> 2;
+        if (q < 2) run32[2 * c + (q == 0 ? 1u : 0u)] = h.head_word;
+        uint32_t w = h.slot;
+#pragma unroll
+        for (int i = 0; i < planes_per_lane; ++i) {
+            if ((h.head_bits >> (31 - i)) & 1u) {
+                run32[w] = planes[i];
+                w += 2;
+            }
+        }
+    }
+};
+
+template<>
+struct coding<uint32_t> {
+    static constexpr int lanes_per_chunk = 2;
+    static constexpr int planes_per_lane = 16;
+    static constexpr uint32_t head_words = hc_size / 32;
+    static constexpr uint32_t w32 = 1;
+    struct held {
+        uint32_t head_bits;  // head bits of this lane's 16 planes in bits 31..16
+        uint32_t head_word;  // the chunk head (stored by the even lane)
+        uint32_t slot;
+    };
+    NDZIP_DEV static uint32_t head_and_count(const uint32_t (&r)[vals], uint32_t &head, uint32_t &unused) {
+        uint32_t own = 0;
+#pragma unroll
+        for (int j = 0; j < vals; ++j) own |= r[j];
+        head = own | pair_swap(own);
+        unused = 0;
+        return static_cast<uint32_t>(__builtin_popcount(head));
+    }
+    NDZIP_DEV static void transpose(const uint32_t (&r)[vals], int t, uint32_t (&planes)[planes_per_lane]) {
+        const bool odd = (t & 1) != 0;
+        // stage 16 of the block-swap network across the lane pair: row j lives in the even lane, row j + 16 in the odd lane
+#pragma unroll
+        for (int j = 0; j < vals; ++j) {
+            const uint32_t got = pair_swap(r[j]);
+            const uint32_t a = odd ? got : r[j], b = odd ? r[j] : got;  // a = row j, b = row j + 16
+            planes[j] = odd ? __builtin_amdgcn_perm(a, b, 0x05040100u)   // row j + 16: (a << 16) | (b & 0x0000ffff)
+                            : __builtin_amdgcn_perm(a, b, 0x07060302u);  // row j:      (a & 0xffff0000) | (b >> 16)
+        }
+        // stages 8, 4, 2, 1 inside the lane (16 rows)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t a = planes[j], b = planes[j + 8];
+            planes[j] = __builtin_amdgcn_perm(a, b, 0x07030501u);      // (a & 0xff00ff00) | ((b >> 8) & 0x00ff00ff)
+            planes[j + 8] = __builtin_amdgcn_perm(a, b, 0x06020400u);  // ((a << 8) & 0xff00ff00) | (b & 0x00ff00ff)
+        }
+        swap_stage<4, 0x0f0f0f0fu, 16>(planes);
+        swap_stage<2, 0x33333333u, 16>(planes);
+        swap_stage<1, 0x55555555u, 16>(planes);
+    }
+    NDZIP_DEV static held hold(int t, uint32_t head, uint32_t, uint32_t chunk_pos) {
+        const bool odd = (t & 1) != 0;
+        held h;
+        h.head_bits = odd ? head << 16 : head;  // even lane: planes 0..15 = head bits 31..16; odd lane: planes 16..31 = bits 15..0
+        h.head_word = head;
+        h.slot = chunk_pos + (odd ? static_cast<uint32_t>(__builtin_popcount(head >> 16)) : 0u);
+        return h;
+    }
+    NDZIP_DEV static void write(const held &h, const uint32_t (&planes)[planes_per_lane], uint32_t *run32, int t) {
+        if ((t & 1) == 0) run32[static_cast<uint32_t>(t) >> 1] = h.head_word;
+        uint32_t w = h.slot;
+#pragma unroll
+        for (int i = 0; i < planes_per_lane; ++i) {
+            if ((h.head_bits >> (31 - i)) & 1u) run32[w++] = planes[i];
+        }
+    }
+};
 
 }  // namespace wide
 }  // namespace ndzip_hip

@@ -728,41 +728,47 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
 #endif
 }
 
-// ---- f64: the register-buffered deferred-write-out pipeline with 256 work-items per hypercube ----------------------
-// Same iteration structure as compress_kernel_db (one hypercube per tile): stage -> B1 -> early prefetch -> stencil -> B2 ->
+// ---- the register-buffered deferred-write-out pipeline with 256 work-items per hypercube ("wide" mapping) ---------
+// Same iteration structure as compress_kernel_db, one hypercube per tile: stage -> B1 -> early prefetch -> stencil -> B2 ->
 // publish -> late prefetch -> plane writes of the previous tile -> transpose of the current one -> look-back (wavefront 0)
-// -> B3 -> copy-out -> B4.  See codec_kernels_wide.hpp for the work-item mapping that makes the registers fit.
+// -> B3 -> copy-out -> B4.  See codec_kernels_wide.hpp for the work-item mapping.
+template<typename W>
 struct wide_cfg {
     static constexpr int threads = wide::threads;
     static constexpr int NW = threads / 64;
-    static constexpr uint32_t smem_bytes = wide::layout::cube_bytes + wide::layout::zero_bytes + 64;
-    static constexpr int min_waves_per_simd = 3;
+    static constexpr uint32_t smem_bytes = wide::layout<W>::cube_bytes + wide::layout<W>::zero_bytes + 64;
+#ifdef NDZIP_EXP_WIDE_WAVES
+    static constexpr int min_waves_per_simd = sizeof(W) == 8 ? 3 : NDZIP_EXP_WIDE_WAVES;
+#else
+    static constexpr int min_waves_per_simd = sizeof(W) == 8 ? 3 : 5;
+#endif
+    static constexpr int early_vectors = wide::input_regs<W>::NV / 2;
 };
 
-template<int Dims, bool Aligned>
-__global__ void __launch_bounds__(wide_cfg::threads, wide_cfg::min_waves_per_simd)
-compress_kernel_wide(const uint64_t *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header, uint64_t *__restrict__ body,
+template<typename W, int Dims, bool Aligned>
+__global__ void __launch_bounds__(wide_cfg<W>::threads, wide_cfg<W>::min_waves_per_simd)
+compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header, W *__restrict__ body,
         tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes, uint32_t *out_len, uint32_t len_extra, uint32_t *err,
         const uint32_t exp_flags_arg, const uint32_t epoch) {
     const desc_ref desc{desc_base, epoch};
     NDZIP_EXP_FLAGS(exp_flags_arg)
-    using L = wide::layout;
-    using W = uint64_t;
-    constexpr int NW = wide_cfg::NW;
-    constexpr int early_vectors = 4;
-    constexpr uint32_t max_hc_words = hc_size + wide::head_words;
+    using C = wide_cfg<W>;
+    using L = wide::layout<W>;
+    using E = wide::coding<W>;
+    constexpr int NW = C::NW;
+    constexpr int early_vectors = C::early_vectors;
+    constexpr uint32_t max_hc_words = hc_size + E::head_words;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x), t = tid;
     const int lane = tid & 63, wave = tid >> 6;
-    const int q = t & 3;                                   // position in the chunk's lane quad
     char *cube = smem;
-    uint32_t *run32 = reinterpret_cast<uint32_t *>(smem);  // later: the encoded run, as uint32 halves of the 64-bit words
+    uint32_t *run32 = reinterpret_cast<uint32_t *>(smem);  // later: the encoded run (f64: as uint32 halves of its words)
     char *zero_region = smem + L::cube_bytes;
     char *zero = zero_region + L::zero_offset;
     uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
 
-    for (uint32_t i = tid; i < L::zero_bytes / 4; i += wide_cfg::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
+    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
 
     const uint32_t ntiles = gg.nhc;
     const uint32_t cls = blockIdx.x % num_classes;
@@ -771,15 +777,16 @@ compress_kernel_wide(const uint64_t *__restrict__ in, const grid_geom gg, uint32
     __syncthreads();
     uint32_t tile = misc[NW + 1] * num_classes + cls;
 
-    wide::input_regs pre;
-    wide::load_regs<Dims, Aligned>(in, gg, hc_origin<Dims>(gg, tile < ntiles ? tile : ntiles - 1), t, pre);
+    wide::input_regs<W> pre;
+    wide::load_regs<W, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, tile < ntiles ? tile : ntiles - 1), t, pre);
 
-    // the previous tile: this lane's 32 plane dwords in registers, aggregate published, waiting for its prefix
+    // the previous tile: this lane's plane words in registers, aggregate published, waiting for its prefix
     bool have_prev = false;
-    uint32_t prev_tile = 0, prev_aggregate = 0, prev_pos = 0, prev_head32 = 0, prev_head_hi = 0, prev_head_lo = 0;
-    uint32_t planes[32];
+    uint32_t prev_tile = 0, prev_aggregate = 0;
+    typename E::held prev_held{};
+    uint32_t planes[E::planes_per_lane];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) planes[j] = 0;
+    for (int j = 0; j < E::planes_per_lane; ++j) planes[j] = 0;
     for (;;) {
         const bool have_cur = tile < ntiles;
         if (!have_cur && !have_prev) break;
@@ -788,28 +795,28 @@ compress_kernel_wide(const uint64_t *__restrict__ in, const grid_geom gg, uint32
         if (have_cur) {
             uint32_t next_ticket = 0;
             if (tid == 0) next_ticket = atomicAdd(ticket_counter, 1u);
-            wide::stage_regs(pre, cube, t);
+            wide::stage_regs<W>(pre, cube, t);
             if (tid == 0) misc[NW + 1] = next_ticket;
         }
         __syncthreads();  // B1: cube staged, next ticket known
         const uint32_t next_tile = have_cur ? misc[NW + 1] * num_classes + cls : tile;
         __builtin_amdgcn_sched_barrier(0);
         const uint64_t next_origin = hc_origin<Dims>(gg, next_tile < ntiles ? next_tile : ntiles - 1);
-        wide::load_regs<Dims, Aligned, 0, early_vectors>(in, gg, next_origin, t, pre);
+        wide::load_regs<W, Dims, Aligned, 0, early_vectors>(in, gg, next_origin, t, pre);
         __builtin_amdgcn_sched_barrier(0);
         W r[wide::vals];
-        uint32_t head_hi = 0, head_lo = 0, count = 0, incl = 0;
+        uint32_t head_a = 0, head_b = 0, count = 0, incl = 0;
         if (have_cur) {
-            wide::stencil<Dims>(cube, zero, t, r);
-            wide::chunk_head(r, head_hi, head_lo);
-            count = static_cast<uint32_t>(__builtin_popcount(head_hi) + __builtin_popcount(head_lo));
-            incl = wave_inclusive_scan(q == 0 ? count : 0u, lane);  // the 4 lanes of a chunk end up with the same value
+            wide::stencil<W, Dims>(cube, zero, t, r);
+            count = E::head_and_count(r, head_a, head_b);
+            // (the lanes of a chunk end up with the same inclusive value: only the first one feeds the scan)
+            incl = wave_inclusive_scan((t & (E::lanes_per_chunk - 1)) == 0 ? count : 0u, lane);
             if (lane == 63) misc[wave] = incl;
         }
         __syncthreads();  // B2: all stencil reads done (staging region reusable), wave totals known
         uint32_t aggregate = 0, chunk_excl = 0;
         if (have_cur) {
-            aggregate = wide::head_words;
+            aggregate = E::head_words;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 const uint32_t total = misc[w];
@@ -820,24 +827,12 @@ compress_kernel_wide(const uint64_t *__restrict__ in, const grid_geom gg, uint32
             if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
         __builtin_amdgcn_sched_barrier(0);
-        wide::load_regs<Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
+        wide::load_regs<W, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
         __builtin_amdgcn_sched_barrier(0);
-        if (have_prev && !(exp_flags & 4u)) {
-            // the previous tile's planes leave the registers: compact them into the (now free) staging region.  Lane
-            // quad of chunk c: lanes 0 / 2 hold the high / low dword of planes 0..31, lanes 1 / 3 of planes 32..63.
-            const uint32_t c = static_cast<uint32_t>(t) >> 2;
-            if (q < 2) run32[2 * c + (q == 0 ? 1u : 0u)] = q == 0 ? prev_head_hi : prev_head_lo;
-            uint32_t w = 2 * prev_pos + ((q & 2) ? 0u : 1u);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                if ((prev_head32 >> (31 - i)) & 1u) {
-                    run32[w] = planes[i];
-                    w += 2;
-                }
-            }
-        }
+        // the previous tile's planes leave the registers: compact them into the (now free) staging region
+        if (have_prev && !(exp_flags & 4u)) E::write(prev_held, planes, run32, t);
         // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
-        if (have_cur) wide::transpose_chunk(r, t, planes);
+        if (have_cur) E::transpose(r, t, planes);
         __builtin_amdgcn_sched_barrier(0);
         if (have_prev && wave == 0) {
             const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * max_hc_words
@@ -847,13 +842,13 @@ compress_kernel_wide(const uint64_t *__restrict__ in, const grid_geom gg, uint32
         __syncthreads();  // B3: previous tile's run complete in LDS, its prefix known
         if (have_prev) {
             const uint32_t prefix = misc[NW];
-            if (!(exp_flags & 2u)) copy_out<W, wide_cfg::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
+            if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
             if (tid == 0) {
                 header[prev_tile] = prefix + prev_aggregate;  // offset_after(hc), common.hh:342-347
                 if (prev_tile == gg.nhc - 1) {
                     if (out_len) *out_len = len_extra + prefix + prev_aggregate;
                     // zero the header pad of 64-bit streams with an odd hypercube count (cuda_codec.inl:446-452)
-                    if (gg.nhc & 1u) header[gg.nhc] = 0;
+                    if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
                 }
             }
         }
@@ -861,10 +856,7 @@ compress_kernel_wide(const uint64_t *__restrict__ in, const grid_geom gg, uint32
         have_prev = have_cur;
         prev_tile = tile;
         prev_aggregate = aggregate;
-        prev_head_hi = head_hi;
-        prev_head_lo = head_lo;
-        prev_head32 = (q & 1) ? head_lo : head_hi;  // the head bits of this lane's 32 planes
-        prev_pos = wide::head_words + chunk_excl + ((q & 1) ? static_cast<uint32_t>(__builtin_popcount(head_hi)) : 0u);
+        prev_held = E::hold(t, head_a, head_b, E::head_words + chunk_excl);
         tile = next_tile;
     }
     release_tickets(tickets, num_classes, tid);
@@ -990,30 +982,32 @@ constexpr uint32_t ticket_classes_for() {
     return max_ticket_classes;
 }
 
-template<int Dims, bool Aligned>
+template<typename W, int Dims, bool Aligned>
 hipError_t launch_compress_wide(const compress_args &a) {
+    using C = wide_cfg<W>;
     const uint32_t ntiles = a.gg.nhc;
     if (ntiles == 0) return hipSuccess;
-    auto kernel = compress_kernel_wide<Dims, Aligned>;
+    auto kernel = compress_kernel_wide<W, Dims, Aligned>;
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int api = 0;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                static_cast<int>(wide_cfg::smem_bytes));
+                static_cast<int>(C::smem_bytes));
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel, wide_cfg::threads, wide_cfg::smem_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel, C::threads, C::smem_bytes);
         if (e != hipSuccess) return e;
-        const int by_lds = static_cast<int>((160u * 1024u) / wide_cfg::smem_bytes);
+        const int by_lds = static_cast<int>((160u * 1024u) / C::smem_bytes);
         blocks_per_cu = api < by_lds ? api : by_lds;
         if (blocks_per_cu < 1) blocks_per_cu = 1;
     }
     static const uint32_t exp_flags = getenv("NDZIP_HIP_EXP") ? static_cast<uint32_t>(atoi(getenv("NDZIP_HIP_EXP"))) : 0u;
-    uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(blocks_per_cu);
+    static const int exp_bpc = getenv("NDZIP_HIP_BPC") ? atoi(getenv("NDZIP_HIP_BPC")) : 0;
+    uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(exp_bpc > 0 && exp_bpc < blocks_per_cu ? exp_bpc : blocks_per_cu);
     if (grid > ntiles) grid = ntiles;
     const uint32_t num_classes = grid < max_ticket_classes ? 1u : max_ticket_classes;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(wide_cfg::threads), wide_cfg::smem_bytes, a.stream, static_cast<const uint64_t *>(a.in), a.gg,
-            a.header, static_cast<uint64_t *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16), num_classes,
-            a.out_len, a.len_extra, a.err, exp_flags, a.epoch);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), C::smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg, a.header,
+            static_cast<W *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16), num_classes, a.out_len,
+            a.len_extra, a.err, exp_flags, a.epoch);
     return hipGetLastError();
 }
 
@@ -1042,10 +1036,20 @@ hipError_t launch_compress_profile(const compress_args &a) {
     } else {
         kernel = compress_kernel<T, Dims, Aligned>;
     }
+    // f64: 256 work-items per hypercube, register-buffered (NDZIP_HIP_NARROW: the single-buffered 128-lane kernel, for
+    // experiments).  The same mapping for f32 -- one 16 KiB hypercube per tile, 96 VGPRs, 5 workgroups per CU -- is correct
+    // but slower than two hypercubes per 256 work-items: twice the tiles means twice the tickets, descriptors and
+    // look-backs (512^3: 0.284 vs 0.208 ms); build with -DNDZIP_EXP_WIDE_F32 and set NDZIP_HIP_WIDE_F32 to try it.
     if constexpr (sizeof(T) == 8) {
-        static const bool narrow = getenv("NDZIP_HIP_F64_NARROW") != nullptr;  // experiments: the single-buffered 128-lane kernel
-        if (!narrow) return launch_compress_wide<Dims, Aligned>(a);
+        static const bool narrow = getenv("NDZIP_HIP_NARROW") != nullptr;
+        if (!narrow) return launch_compress_wide<W, Dims, Aligned>(a);
     }
+#ifdef NDZIP_EXP_WIDE_F32
+    if constexpr (sizeof(T) == 4) {
+        static const bool wide_f32 = getenv("NDZIP_HIP_WIDE_F32") != nullptr;
+        if (wide_f32) return launch_compress_wide<W, Dims, Aligned>(a);
+    }
+#endif
     // persistent grid, fully resident: bounded by the occupancy query and by what the LDS alone admits
     static int blocks_per_cu_of[2] = {0, 0};
     int &blocks_per_cu = blocks_per_cu_of[paired ? 1 : 0];
@@ -1131,7 +1135,7 @@ int compress_hcs_per_group<T_>(int) {
 
 template<>
 uint32_t compress_num_tiles<T_>(int, uint32_t nhc) {
-    return (nhc + tile_cfg<T_, 1>::K - 1) / tile_cfg<T_, 1>::K;
+    return nhc;  // descriptors for the finest tiling any kernel variant uses (one hypercube per tile)
 }
 
 template<>

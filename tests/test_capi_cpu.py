@@ -101,7 +101,7 @@ def test_compress_and_decompress_kernels_do_not_spill():
         build.build(force=True)
         res = build.kernel_resources()
     hot = {k: v for k, v in res.items() if "compress_kernel" in k}  # compress_kernel, compress_kernel_db, decompress_kernel
-    assert len(hot) >= 24, sorted(res)
+    assert len(hot) >= 30, sorted(res)  # f32 db (7) + f64 wide (6) + f64 narrow (6) + decompress (12)
     for name, r in hot.items():
         assert r["scratch"] == 0, f"{name} spills {r['scratch']} bytes per lane"
     f32_db = [v for k, v in hot.items() if "compress_kernel_dbIf" in k]
