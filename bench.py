@@ -12,7 +12,7 @@ per-GPU work fixed); the only exchange is the RCCL all-gather of one length per 
 came out of decompress, over all ranks, divided by the wall time of the K timed steps (max over ranks).
 
 Extra objects:
-  roofline      dominant kernel = compress_kernel<float,3>: algorithmic bytes (raw in + stream out) per launch over
+  roofline      dominant kernel = compress_kernel_db<float,3> (compress_kernel_wide<u64,D> for float64 runs): algorithmic bytes (raw in + stream out) per launch over
                 the HIP-event duration of the launch on the stream it runs on; peak 8 TB/s (HBM3E spec).
   cpu_baseline  this repo's OpenMP port of the reference CPU path (oracle/, bit-exact with the compiled
                 reference) timed on the host cores of the same box on the same grid; plus the genuine reference
@@ -260,7 +260,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"compress_kernel<{'float' if wb == 4 else 'double'},{dims}>",
+                "kernel": f"compress_kernel_db<float,{dims}>" if wb == 4 else f"compress_kernel_wide<unsigned long,{dims}>",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
