@@ -14,7 +14,8 @@ using tile_desc = unsigned long long;
 
 // Scratch behind the descriptors: 16 experiment counters, then one ticket counter per class, each in its own 128-byte
 // line (see max_ticket_classes in codec_launch.inl).  Sizes in tile_desc units.
-constexpr unsigned max_ticket_classes = 16;
+constexpr unsigned max_ticket_classes = 64;      // counters reserved in the scratch
+constexpr unsigned default_ticket_classes = 16;  // classes a launch uses
 constexpr unsigned ticket_stride_words = 32;  // uint32 words between the counters of consecutive classes
 constexpr unsigned scratch_extra_descs = 16 + (max_ticket_classes + 1) * ticket_stride_words / 2;  // + the 'workgroups done' line
 
