@@ -703,12 +703,15 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
                 for (int j = 0; j < 4; ++j) r[4 * i + j] = v.w[j];
             }
         } else {
+            // walk the present planes: the word at the running position is read speculatively (always inside the run or
+            // the staging region) and kept iff the plane's head bit is set
+            uint32_t pos = base;
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                // planes above i that are present = set head bits among the top i bits
-                const uint32_t above = i == 0 ? 0u : (head & ~(0xffffffffu >> i));
-                const uint32_t w = in32[base + static_cast<uint32_t>(__builtin_popcount(above))];
-                r[i] = ((head >> (31 - i)) & 1u) ? w : 0u;
+                const uint32_t bit = (head >> (31 - i)) & 1u;
+                const uint32_t w = in32[pos];
+                r[i] = w & (0u - bit);
+                pos += bit;
             }
         }
         if constexpr (ComplementInPlaneDomain) {
@@ -863,16 +866,20 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
         // work-item = (y, pair of x) for all 16 z
         const uint32_t y = static_cast<uint32_t>(t) >> 3, xp = static_cast<uint32_t>(t) & 7u;
         W acc0 = 0, acc1 = 0;
+        // one global pointer advanced by a plane per step and one LDS base with immediate offsets (a plane is 8 padded
+        // chunks): no per-step 64-bit multiply-adds
+        W *dst = out + origin + static_cast<uint64_t>(y) * gg.stride[1] + 2 * xp;
+        const char *src = cube + L::off(y * 16 + 2 * xp);
+        constexpr uint32_t plane_bytes = L::off(256);
 #pragma unroll
-        for (uint32_t z = 0; z < 16; ++z) {
-            const uint32_t k = z * 256 + y * 16 + 2 * xp;
-            const char *p = cube + L::off(k);
-            const uint64_t g = origin + static_cast<uint64_t>(z) * gg.stride[0] + static_cast<uint64_t>(y) * gg.stride[1] + 2 * xp;
+        for (uint32_t z = 0; z < 16; ++z, dst += gg.stride[0]) {
+            const char *p = src + z * plane_bytes;
+            W *const gp = dst;
             if constexpr (sizeof(W) == 4) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(p);
                 acc0 += v.x;
                 acc1 += v.y;
-                global_store8<Aligned>(out + g, rotr1(acc0), rotr1(acc1));
+                global_store8<Aligned>(gp, rotr1(acc0), rotr1(acc1));
             } else {
                 const vec16 v = lds_read16(p);
                 acc0 += static_cast<uint64_t>(v.w[0]) | (static_cast<uint64_t>(v.w[1]) << 32);
@@ -883,7 +890,7 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
                 w.w[1] = static_cast<uint32_t>(o0 >> 32);
                 w.w[2] = static_cast<uint32_t>(o1);
                 w.w[3] = static_cast<uint32_t>(o1 >> 32);
-                global_store16<Aligned>(out + g, w);
+                global_store16<Aligned>(gp, w);
             }
         }
     }
