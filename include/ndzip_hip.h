@@ -100,6 +100,13 @@ NDZIP_HIP_API int ndzip_hip_compressor_offset_header_device(
         ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, const uint32_t *d_base);
 
 /* Reads and clears the handle's sticky device error word; synchronises the handle's stream. */
+/* The same with the base computed on the device from the all-gathered shard lengths: base of shard `rank` = sum over
+ * r < rank of (d_lengths[r] - d_borders[r]) (words written by compress_split incl. the shard's border, minus its border
+ * words); the base is also stored to *d_base_out (may be NULL) for ndzip_hip_decompressor_decompress_split.  One launch
+ * between the two collectives of the multi-GPU path, no host synchronisation. */
+NDZIP_HIP_API int ndzip_hip_compressor_offset_header_gathered(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count,
+        const uint32_t *d_lengths, const uint32_t *d_borders, uint32_t rank, uint32_t *d_base_out);
+
 NDZIP_HIP_API int ndzip_hip_compressor_check(ndzip_hip_compressor *c);
 
 NDZIP_HIP_API int ndzip_hip_compressor_destroy(ndzip_hip_compressor *c);

@@ -123,6 +123,16 @@ __global__ void offset_header_device_kernel(uint32_t *header, uint32_t count, co
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += b;
 }
 
+// base of shard `rank` = sum over lower ranks of (body words incl. border - border words), from the all-gathered lengths;
+// added to the shard's header entries and left in *base_out for the decoder (one launch instead of a dozen tensor ops)
+__global__ void offset_header_gathered_kernel(uint32_t *header, uint32_t count, const uint32_t *lengths, const uint32_t *borders,
+        uint32_t rank, uint32_t *base_out) {
+    uint32_t base = 0;
+    for (uint32_t r = 0; r < rank; ++r) base += lengths[r] - borders[r];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += base;
+    if (base_out && blockIdx.x == 0 && threadIdx.x == 0) *base_out = base;
+}
+
 template<bool Pack>
 hipError_t launch_border(int dtype, void *data, void *body, const uint32_t *header, uint32_t nhc, const uint32_t *header_base,
         const border_geom &bg, uint32_t *out_len, uint32_t len_extra, hipStream_t stream) {
@@ -310,6 +320,18 @@ int ndzip_hip_compressor_offset_header_device(ndzip_hip_compressor *c, uint32_t 
     uint32_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(offset_header_device_kernel, dim3(blocks), dim3(256), 0, c->stream, d_header, count, d_base);
+    HIP_TRY(hipGetLastError());
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_compressor_offset_header_gathered(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, const uint32_t *d_lengths,
+        const uint32_t *d_borders, uint32_t rank, uint32_t *d_base_out) {
+    if (!c || (!d_header && count) || !d_lengths || !d_borders) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    uint32_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;  // still publishes the base
+    hipLaunchKernelGGL(offset_header_gathered_kernel, dim3(blocks), dim3(256), 0, c->stream, d_header, count, d_lengths, d_borders, rank,
+            d_base_out);
     HIP_TRY(hipGetLastError());
     return NDZIP_HIP_OK;
 }

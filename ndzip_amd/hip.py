@@ -52,6 +52,7 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_compressor_compress_split",
     "ndzip_hip_compressor_offset_header",
     "ndzip_hip_compressor_offset_header_device",
+    "ndzip_hip_compressor_offset_header_gathered",
     "ndzip_hip_compressor_check",
     "ndzip_hip_compressor_destroy",
     "ndzip_hip_decompressor_create",
@@ -105,6 +106,7 @@ def lib():
     L.ndzip_hip_compressor_compress_split.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _U32P, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ndzip_hip_compressor_offset_header.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     L.ndzip_hip_compressor_offset_header_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ndzip_hip_compressor_offset_header_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ndzip_hip_compressor_check.argtypes = [C.c_void_p]
     L.ndzip_hip_compressor_destroy.argtypes = [C.c_void_p]
     L.ndzip_hip_decompressor_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -237,6 +239,10 @@ class HipCompressor:
 
     def offset_header_device(self, device_header, count: int, device_base) -> None:
         _check(lib().ndzip_hip_compressor_offset_header_device(self._h, _ptr(device_header), count, _ptr(device_base)))
+
+    def offset_header_gathered(self, device_header, count: int, device_lengths, device_borders, rank: int, device_base_out=None) -> None:
+        _check(lib().ndzip_hip_compressor_offset_header_gathered(self._h, _ptr(device_header), count, _ptr(device_lengths),
+                                                                 _ptr(device_borders), rank, _ptr(device_base_out)))
 
     def check(self) -> None:
         _check(lib().ndzip_hip_compressor_check(self._h))

@@ -5,8 +5,9 @@ The reference has no distributed runtime; this follows SUR
   * the slowest dimension is cut into `world` slabs whose thickness is a multiple of the hypercube side, so a
     slab is a contiguous sub-array with a contiguous hypercube-index range and no halo;
   * every rank compresses its slab with LOCAL offsets (ndzip_hip_compressor_compress_split);
-  * the only exchange is an all-gather of one body length per rank (-> exclusive prefix = the rank's global
-    word offset) and an all-gather of the header segments after the base has been added.  Bodies never move:
+  * the only exchange is an all-gather of one uint32 body length per rank (-> exclusive prefix = the rank's global
+    word offset, computed and added to the rank's header entries by ONE kernel) and an all-gather of the header
+    segments after that.  Bodies never move:
     rank r's body lives at global body offset base_r, and the global stream is the concatenation
     [header][body_0]...[body_{R-1}][border_0]...[border_{R-1}] -- a host/file-level operation outside the
     timed region (`assemble_stream`), byte-identical to the single-GPU stream;
@@ -66,33 +67,6 @@ def plan_shards(extent: Sequence[int], world: int) -> List[Shard]:
     return shards
 
 
-def exchange_offsets(local_body_words, rank: int, world: int, group=None):
-    """All-gather one length per rank; returns (base, total, lengths) as tensors on the input's device:
-    base = sum of the lengths of lower ranks (this rank's global body word offset).  RCCL/gloo message:
-    world x 8 bytes."""
-    import torch
-    import torch.distributed as dist
-
-    mine = local_body_words.reshape(1).to(torch.int64)
-    if world == 1:
-        lens = mine.clone()
-    else:
-        lens = torch.empty(world, dtype=torch.int64, device=mine.device)
-        dist.all_gather_into_tensor(lens, mine, group=group)
-    csum = torch.cumsum(lens, 0)
-    base = csum[rank] - lens[rank]
-    return base, csum[-1], lens
-
-
-def wrap_u32_to_i32(x):
-    """uint32 value held in an int64 tensor -> the int32 tensor with the same bits (torch has no uint32 math)."""
-    import torch
-
-    v = x.reshape(1).to(torch.int64)
-    v = torch.where(v >= 2 ** 31, v - 2 ** 32, v)
-    return v.to(torch.int32)
-
-
 def gather_headers(local_header,shard_sizes: Sequence[int], world: int, group=None):
     """All-gather the (already globalised) header segments into the full header on every rank.
     local_header: int32 tensor with this rank's entries.  Unequal segments are padded to the maximum."""
@@ -115,11 +89,23 @@ def gather_headers(local_header,shard_sizes: Sequence[int], world: int, group=No
     return torch.cat([out[r * m: r * m + shard_sizes[r]] for r in range(world)])
 
 
+def base_from_lengths(lengths, borders, rank: int) -> int:
+    """Global word offset of shard `rank`'s body: sum over lower ranks of (words written incl. border - border words), in
+    uint32 arithmetic.  Host restatement of offset_header_gathered_kernel (tests; the GPU path computes it in that kernel)."""
+    base = 0
+    for r in range(rank):
+        base = (base + (int(lengths[r]) & 0xFFFFFFFF) - int(borders[r])) & 0xFFFFFFFF
+    return base
+
+
 class ShardedCodec:
     """Per-rank driver of the sharded compress / decompress path on one GPU.
 
-    All buffers are allocated once; compress() and decompress() enqueue work on the current torch stream and
-    on the process group's stream only (no host synchronisation inside)."""
+    All buffers are allocated once; compress() and decompress() enqueue work on the current torch stream and on the
+    process group's stream only (no host synchronisation inside).  compress() = three steps with one collective between
+    each: compress_local -> all-gather of one uint32 length per rank -> globalise (ONE kernel: base from the gathered
+    lengths, added to the local header entries) -> all-gather of the header segments.  The steps are public so that a test
+    can play every rank of a plan on one GPU."""
 
     def __init__(self, dtype, global_extent: Sequence[int], rank: int, world: int, device, group=None):
         import numpy as np
@@ -142,35 +128,42 @@ class ShardedCodec:
         bound = ndzip_amd.compressed_length_bound(dtype, self.shard.extent) - ndzip_amd.header_words(dtype, nhc)
         self.header_local = torch.zeros(max(1, nhc + 1), dtype=torch.int32, device=device)
         self.body = torch.zeros(max(1, bound), dtype=self.words_per_elem_t, device=device)
-        self.body_len = torch.zeros(1, dtype=torch.int32, device=device)
-        self.base32 = torch.zeros(1, dtype=torch.int32, device=device)
+        self.body_len = torch.zeros(1, dtype=torch.int32, device=device)     # uint32 bits: words written incl. the local border
+        self.base32 = torch.zeros(1, dtype=torch.int32, device=device)       # uint32 bits: global word offset of this body
+        self.lens_all = torch.zeros(world, dtype=torch.int32, device=device)  # all-gathered body_len
+        self.borders = torch.tensor([s.border for s in self.shards], dtype=torch.int64, device=device).to(torch.int32)
+        self.sizes = [s.num_hypercubes for s in self.shards]
         self.header_global: Optional["torch.Tensor"] = None
-        self.base = None
-        self.total = None
 
-    def compress(self, local_in, kernel_events=None) -> None:
-        """local_in: this rank's slab (device tensor).  Afterwards: self.header_global (all NHC entries, global
-        offsets), self.body / self.body_len (resident body + local border), self.base (global word offset).
+    # ---- the three steps of compress ----------------------------------------------------------------------------
+    def compress_local(self, local_in, kernel_events=None) -> None:
+        """local_in: this rank's slab (device tensor) -> header_local (LOCAL offsets), body, body_len.
         kernel_events: optional (start, stop) torch.cuda.Event pair recorded tightly around the codec launch."""
-        import torch
-
-        sh = self.shard
         if kernel_events:
             kernel_events[0].record()
-        self.compressor.compress_split(local_in, sh.extent, self.header_local, self.body, self.body_len)
+        self.compressor.compress_split(local_in, self.shard.extent, self.header_local, self.body, self.body_len)
         if kernel_events:
             kernel_events[1].record()
+
+    def globalise(self) -> None:
+        """lens_all (every rank's body_len) -> header_local holds GLOBAL offsets, base32 this rank's base."""
+        self.compressor.offset_header_gathered(self.header_local, self.shard.num_hypercubes, self.lens_all, self.borders, self.rank,
+                                               self.base32)
+
+    def compress(self, local_in, kernel_events=None) -> None:
+        """Afterwards: self.header_global (all NHC entries, global offsets), self.body / self.body_len (resident body + local
+        border), self.base32 (global word offset)."""
+        import torch.distributed as dist
+
+        sh = self.shard
+        self.compress_local(local_in, kernel_events)
         if self.world == 1:
             # single shard: local offsets are global offsets, nothing to exchange
             self.header_global = self.header_local[: sh.num_hypercubes]
             return
-        # body words without the local border: the border count is known analytically
-        body_only = (self.body_len.to(torch.int64) & 0xFFFFFFFF) - sh.border  # the length word is a uint32
-        self.base, self.total, self.lens = exchange_offsets(body_only, self.rank, self.world, self.group)
-        self.base32.copy_(wrap_u32_to_i32(self.base))
-        self.compressor.offset_header_device(self.header_local, sh.num_hypercubes, self.base32)
-        sizes = [s.num_hypercubes for s in self.shards]
-        self.header_global = gather_headers(self.header_local[: sh.num_hypercubes], sizes, self.world, self.group)
+        dist.all_gather_into_tensor(self.lens_all, self.body_len, group=self.group)   # world x 4 bytes
+        self.globalise()
+        self.header_global = gather_headers(self.header_local[: sh.num_hypercubes], self.sizes, self.world, self.group)
 
     def decompress(self, local_out) -> None:
         """Decode this rank's slab from (global header slice, base, resident body).  The base stays on the

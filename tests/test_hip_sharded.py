@@ -76,3 +76,43 @@ def test_sharded_codec_single_rank(hiplib, cuda_device):
     n = int(codec.body_len.cpu()[0])
     got = assemble_stream(np.float32, extent, codec.header_global.cpu().numpy().view(np.uint32), [codec.body[:n].cpu().numpy()], [n], codec.shards)
     assert np.array_equal(got, oracle.compress(data))
+
+
+@pytest.mark.parametrize("extent,dtype,world", [((96, 64, 48), np.float32, 3), ((256, 200), np.float64, 4), ((8 * 4096 + 3,), np.float32, 2),
+                                                  ((50, 37, 41), np.float32, 2)])
+def test_every_rank_of_a_plan_on_one_gpu(hiplib, cuda_device, extent, dtype, world):
+    """The N > 1 path of ShardedCodec, step by step, with the two collectives replaced by their definition (concatenate what
+    every rank contributes): compress_local on every rank, all-gather of the lengths, globalise (the fused base + offset
+    kernel, checked against its host restatement), all-gather of the header segments, assemble, decode every slab."""
+    import torch
+
+    from ndzip_amd.sharded import base_from_lengths
+
+    full = synth_numpy(extent, dtype, seed=21, noise_mask=0xFF)
+    codecs = [ShardedCodec(dtype, extent, r, world, cuda_device) for r in range(world)]
+    slabs = [torch.from_numpy(np.ascontiguousarray(full[c.shard.start0: c.shard.start0 + c.shard.extent[0]])).to(cuda_device) for c in codecs]
+    for rep in range(2):  # twice: the handles are reused (descriptor epochs, ticket counters)
+        for c, slab in zip(codecs, slabs):
+            c.compress_local(slab)
+        lens_all = torch.cat([c.body_len for c in codecs])            # == all_gather_into_tensor(lens_all, body_len)
+        for c in codecs:
+            c.lens_all.copy_(lens_all)
+            c.globalise()
+        segments = [c.header_local[: c.shard.num_hypercubes] for c in codecs]
+        header_global = torch.cat(segments)                            # == gather_headers(...)
+        for c in codecs:
+            c.header_global = header_global
+            c.check()
+        lens = lens_all.cpu().numpy().view(np.uint32)
+        borders = [c.shard.border for c in codecs]
+        for r, c in enumerate(codecs):
+            assert int(c.base32.cpu().numpy().view(np.uint32)[0]) == base_from_lengths(lens, borders, r)
+        got = assemble_stream(dtype, extent, header_global.cpu().numpy().view(np.uint32), [c.body.cpu().numpy() for c in codecs],
+                              [int(x) for x in lens], codecs[0].shards)
+        want = oracle.compress(full)
+        assert len(got) == len(want) and np.array_equal(got, want)
+        for c, slab in zip(codecs, slabs):
+            out = torch.zeros_like(slab)
+            c.decompress(out)
+            c.check()
+            assert torch.equal(out.view(torch.uint8), slab.view(torch.uint8))

@@ -1,6 +1,6 @@
 """CPU suite for the multi-GPU path: shard planning and, with two gloo processes, the offset exchange +
 header gather.  The per-rank codec is the ORACLE here (this is a test of the host logic), the collectives are the very
-functions the GPU path uses (ndzip_amd.sharded.exchange_offsets / gather_headers / assemble_stream)."""
+functions the GPU path uses (the length all-gather, ndzip_amd.sharded.base_from_lengths / gather_headers / assemble_stream)."""
 import os
 import socket
 
@@ -42,7 +42,7 @@ def _rank_main(rank, world, port, extent, dtype_name, out_dir):
     import torch
     import torch.distributed as dist
 
-    from ndzip_amd.sharded import exchange_offsets, gather_headers, wrap_u32_to_i32
+    from ndzip_amd.sharded import base_from_lengths, gather_headers
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -59,10 +59,16 @@ def _rank_main(rank, world, port, extent, dtype_name, out_dir):
     hw = (nhc + (1 if wdt == np.uint32 else 2) - 1) // (1 if wdt == np.uint32 else 2)
     header_local = np.frombuffer(stream.tobytes(), dtype=np.uint32)[:nhc].copy()
     body = stream[hw:]
-    body_only = torch.tensor([len(body) - sh.border], dtype=torch.int64)
-    base, total, lens = exchange_offsets(body_only, rank, world)
-    hdr = torch.from_numpy(header_local.view(np.int32)) + wrap_u32_to_i32(base)
+    # the exchange of ShardedCodec.compress: all-gather of one uint32 length (words incl. the local border) per rank ...
+    body_len = torch.tensor([len(body)], dtype=torch.int32)
+    lens_all = torch.zeros(world, dtype=torch.int32)
+    dist.all_gather_into_tensor(lens_all, body_len)
+    # ... the base (host restatement of the fused kernel) added to the local entries ...
+    base = base_from_lengths(lens_all.numpy().view(np.uint32), [s.border for s in shards], rank)
+    hdr = torch.from_numpy(((header_local.astype(np.uint64) + base) & 0xFFFFFFFF).astype(np.uint32).view(np.int32))
+    # ... and the all-gather of the header segments
     header_global = gather_headers(hdr, [s.num_hypercubes for s in shards], world)
+    total = int(sum(int(x) - s.border for x, s in zip(lens_all.numpy().view(np.uint32), shards)))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), header=header_global.numpy().view(np.uint32), body=body.view(wdt), base=int(base), total=int(total))
     dist.destroy_process_group()
 
