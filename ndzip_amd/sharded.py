@@ -133,7 +133,8 @@ class ShardedCodec:
         self.lens_all = torch.zeros(world, dtype=torch.int32, device=device)  # all-gathered body_len
         self.borders = torch.tensor([s.border for s in self.shards], dtype=torch.int64, device=device).to(torch.int32)
         self.sizes = [s.num_hypercubes for s in self.shards]
-        self.header_global: Optional["torch.Tensor"] = None
+        self._header_global: Optional["torch.Tensor"] = None
+        self._pending = None  # the header all-gather still in flight on the process group's stream
 
     # ---- the three steps of compress ----------------------------------------------------------------------------
     def compress_local(self, local_in, kernel_events=None) -> None:
@@ -150,29 +151,56 @@ class ShardedCodec:
         self.compressor.offset_header_gathered(self.header_local, self.shard.num_hypercubes, self.lens_all, self.borders, self.rank,
                                                self.base32)
 
+    def finish(self) -> None:
+        """Wait (stream-wise) for the header all-gather of the last compress()."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+    @property
+    def header_global(self):
+        """All NHC header entries with global offsets (complete once the last compress()'s all-gather has landed)."""
+        self.finish()
+        return self._header_global
+
+    @header_global.setter
+    def header_global(self, value) -> None:
+        self._header_global = value
+
     def compress(self, local_in, kernel_events=None) -> None:
         """Afterwards: self.header_global (all NHC entries, global offsets), self.body / self.body_len (resident body + local
-        border), self.base32 (global word offset)."""
+        border), self.base32 (global word offset).  The header all-gather is left in flight (it needs nothing from, and nothing
+        that follows on this rank needs anything from it: this rank's own entries are already global in header_local); it is
+        waited for by finish(), by reading header_global, and before the next compress() overwrites its input."""
+        import torch
         import torch.distributed as dist
 
         sh = self.shard
+        self.finish()
         self.compress_local(local_in, kernel_events)
         if self.world == 1:
             # single shard: local offsets are global offsets, nothing to exchange
-            self.header_global = self.header_local[: sh.num_hypercubes]
+            self._header_global = self.header_local[: sh.num_hypercubes]
             return
         dist.all_gather_into_tensor(self.lens_all, self.body_len, group=self.group)   # world x 4 bytes
         self.globalise()
-        self.header_global = gather_headers(self.header_local[: sh.num_hypercubes], self.sizes, self.world, self.group)
+        m = max(self.sizes)
+        if m > 0 and all(n == m for n in self.sizes):
+            if self._header_global is None or self._header_global.numel() != self.world * m:
+                self._header_global = torch.empty(self.world * m, dtype=torch.int32, device=self.device)
+            self._pending = dist.all_gather_into_tensor(self._header_global, self.header_local[:m], group=self.group, async_op=True)
+        else:
+            self._header_global = gather_headers(self.header_local[: sh.num_hypercubes], self.sizes, self.world, self.group)
 
     def decompress(self, local_out) -> None:
-        """Decode this rank's slab from (global header slice, base, resident body).  The base stays on the
-        device: it is this rank's `base32` word (== the previous shard's last header entry)."""
+        """Decode this rank's slab from (its header entries with global offsets, its base, its resident body).  The entries
+        are header_local after globalise() == header_global[hc_begin:hc_end]; the base stays on the device (`base32` == the
+        previous shard's last header entry).  No collective and no dependence on the header all-gather."""
         sh = self.shard
-        hdr = self.header_global[sh.hc_begin: sh.hc_end] if sh.num_hypercubes else self.header_local
-        self.decompressor.decompress_split(hdr, self.base32, self.body, local_out, sh.extent)
+        self.decompressor.decompress_split(self.header_local, self.base32, self.body, local_out, sh.extent)
 
     def check(self) -> None:
+        self.finish()
         self.compressor.check()
         self.decompressor.check()
 

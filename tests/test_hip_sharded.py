@@ -103,6 +103,8 @@ def test_every_rank_of_a_plan_on_one_gpu(hiplib, cuda_device, extent, dtype, wor
         for c in codecs:
             c.header_global = header_global
             c.check()
+            # a rank decodes from its own entries: they must be exactly its slice of the global header
+            assert torch.equal(c.header_local[: c.shard.num_hypercubes], header_global[c.shard.hc_begin: c.shard.hc_end])
         lens = lens_all.cpu().numpy().view(np.uint32)
         borders = [c.shard.border for c in codecs]
         for r, c in enumerate(codecs):
