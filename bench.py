@@ -133,11 +133,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus > 1 launch with python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # NDZIP_BENCH_SHARE_GPU=1 (self-test on a one-GPU box only): every rank uses cuda:0 and the group is gloo -- RCCL
+    # refuses two ranks on one device; same code path otherwise
+    share_gpu = world > 1 and os.environ.get("NDZIP_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     per_gpu = tuple(int(x) for x in args.shape.split(","))
     dims = len(per_gpu)

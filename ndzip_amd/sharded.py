@@ -18,6 +18,7 @@ device tensors) on the GPU box and over gloo (CPU tensors) in the world_size-2 C
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -185,7 +186,9 @@ class ShardedCodec:
         dist.all_gather_into_tensor(self.lens_all, self.body_len, group=self.group)   # world x 4 bytes
         self.globalise()
         m = max(self.sizes)
-        if m > 0 and all(n == m for n in self.sizes):
+        # NDZIP_SHARDED_ASYNC_GATHER=1 leaves the header all-gather in flight behind decompress (opt-in until it has run on a
+        # multi-GPU node; the default issues it synchronously on the process group's stream)
+        if m > 0 and all(n == m for n in self.sizes) and os.environ.get("NDZIP_SHARDED_ASYNC_GATHER") == "1":
             if self._header_global is None or self._header_global.numel() != self.world * m:
                 self._header_global = torch.empty(self.world * m, dtype=torch.int32, device=self.device)
             self._pending = dist.all_gather_into_tensor(self._header_global, self.header_local[:m], group=self.group, async_op=True)
