@@ -108,3 +108,29 @@ def test_compress_and_decompress_kernels_do_not_spill():
     assert f32_db and all(r["occupancy"] >= 3 for r in f32_db)       # 3 workgroups of 4 wavefronts per CU
     dec = [v for k, v in hot.items() if "decompress_kernelIf" in k]
     assert dec and all(r["occupancy"] >= 5 for r in dec)                 # LDS admits 4 workgroups of 4 wavefronts per CU anyway
+
+
+def test_pipelined_offloader_validates_arguments_before_touching_the_device():
+    """ndzip_hip_offloader_create: argument errors are reported as such (not as a missing device), and without a device the call
+    fails loudly -- there is no CPU fallback behind the persistent host-pointer interface either."""
+    import ctypes as C
+
+    L = hip.lib()
+    h = C.c_void_p()
+    ext = (C.c_uint32 * 3)(64, 64, 64)
+    assert L.ndzip_hip_offloader_create(hip.F32, 3, ext, 2, None) == hip.ERR_INVALID_ARGUMENT
+    assert L.ndzip_hip_offloader_create(7, 3, ext, 2, C.byref(h)) == hip.ERR_INVALID_ARGUMENT
+    assert L.ndzip_hip_offloader_create(hip.F32, 4, ext, 2, C.byref(h)) == hip.ERR_INVALID_ARGUMENT
+    assert b"Invalid dimensionality" in L.ndzip_hip_last_error()
+    assert L.ndzip_hip_offloader_create(hip.F32, 3, ext, 0, C.byref(h)) == hip.ERR_INVALID_ARGUMENT
+    assert L.ndzip_hip_offloader_create(hip.F32, 3, ext, 17, C.byref(h)) == hip.ERR_INVALID_ARGUMENT
+    assert L.ndzip_hip_offloader_create(hip.F32, 3, None, 2, C.byref(h)) == hip.ERR_INVALID_ARGUMENT
+    assert L.ndzip_hip_offloader_wait(None, 0, None, None) == hip.ERR_INVALID_ARGUMENT
+    assert L.ndzip_hip_offloader_submit_compress(None, 0, ext, None, None) == hip.ERR_INVALID_ARGUMENT
+    assert L.ndzip_hip_offloader_destroy(None) == hip.OK and L.ndzip_hip_host_free(None) == hip.OK
+    if not os.path.exists("/dev/kfd"):
+        assert L.ndzip_hip_offloader_create(hip.F32, 3, ext, 2, C.byref(h)) == hip.ERR_NO_DEVICE and not h.value
+        p = C.c_void_p()
+        assert L.ndzip_hip_host_alloc(4096, C.byref(p)) == hip.ERR_NO_DEVICE and not p.value
+        with pytest.raises(ndzip_amd.NdzipHipError, match="no CPU fallback"):
+            ndzip_amd.HipPipelinedOffloader(np.float32, (64, 64, 64))
