@@ -68,9 +68,10 @@ def plan_shards(extent: Sequence[int], world: int) -> List[Shard]:
     return shards
 
 
-def gather_headers(local_header,shard_sizes: Sequence[int], world: int, group=None):
+def gather_headers(local_header, shard_sizes: Sequence[int], world: int, group=None, out=None):
     """All-gather the (already globalised) header segments into the full header on every rank.
-    local_header: int32 tensor with this rank's entries.  Unequal segments are padded to the maximum."""
+    local_header: int32 tensor with this rank's entries.  Unequal segments are padded to the maximum.
+    out: optional preallocated int32 tensor of world * max(shard_sizes) entries, used (and returned) when all segments are equal."""
     import torch
     import torch.distributed as dist
 
@@ -80,7 +81,8 @@ def gather_headers(local_header,shard_sizes: Sequence[int], world: int, group=No
     if m == 0:
         return local_header.clone()
     if all(s == m for s in shard_sizes):
-        out = torch.empty(world * m, dtype=local_header.dtype, device=local_header.device)
+        if out is None or out.numel() != world * m or out.dtype != local_header.dtype or out.device != local_header.device:
+            out = torch.empty(world * m, dtype=local_header.dtype, device=local_header.device)
         dist.all_gather_into_tensor(out, local_header.contiguous(), group=group)
         return out
     padded = torch.zeros(m, dtype=local_header.dtype, device=local_header.device)
@@ -193,7 +195,9 @@ class ShardedCodec:
                 self._header_global = torch.empty(self.world * m, dtype=torch.int32, device=self.device)
             self._pending = dist.all_gather_into_tensor(self._header_global, self.header_local[:m], group=self.group, async_op=True)
         else:
-            self._header_global = gather_headers(self.header_local[: sh.num_hypercubes], self.sizes, self.world, self.group)
+            # (the buffer of the previous step is reused: no allocation per step on the collective's path)
+            self._header_global = gather_headers(self.header_local[: sh.num_hypercubes], self.sizes, self.world, self.group,
+                                                 out=self._header_global)
 
     def decompress(self, local_out) -> None:
         """Decode this rank's slab from (its header entries with global offsets, its base, its resident body).  The entries
