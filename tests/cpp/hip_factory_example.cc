@@ -1,0 +1,8 @@
+// tests/cpp/hip_factory_example.cc -- the translation unit INTEGRATION.md section 2 proposes for the reference tree
+// (src/ndzip/hip_factory.cc), compiled against the reference's own headers by tests/test_cpp_adaptor.py.
+#include <cassert>
+#include <stdexcept>
+#define NDZIP_HIP_WITH_REFERENCE_HEADERS 1  // adaptor uses ndzip::extent / offloader<T> / compressor_requirements
+#include <ndzip_hip.hh>
+template std::unique_ptr<ndzip::offloader<float>> ndzip::make_hip_offloader<float>(ndzip::dim_type);
+template std::unique_ptr<ndzip::offloader<double>> ndzip::make_hip_offloader<double>(ndzip::dim_type);

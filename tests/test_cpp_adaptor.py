@@ -22,6 +22,19 @@ def test_adaptor_compiles_against_reference_headers():
     assert r.returncode == 0, r.stderr
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include/ndzip"), reason="reference tree only exists in the authoring container")
+def test_integration_factory_unit_compiles_in_the_reference_tree(tmp_path):
+    """the proposed src/ndzip/hip_factory.cc builds to an object against the reference's headers and
+    defines the two factory instantiations the reference's make_offloader switch would call."""
+    obj = str(tmp_path / "hip_factory.o")
+    r = subprocess.run(["g++", "-std=c++17", "-c", "-I" + os.path.join(ROOT, "include"), "-I/root/reference/include",
+                        os.path.join(ROOT, "tests", "cpp", "hip_factory_example.cc"), "-o", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True, check=True).stdout
+    assert "ndzip::make_hip_offloader<float>(int)" in syms or "make_hip_offloader<float>" in syms
+    assert "make_hip_offloader<double>" in syms
+
+
 @pytest.mark.gpu
 def test_adaptor_roundtrip_on_gpu(tmp_path):
     exe = str(tmp_path / "adaptor_rt")
