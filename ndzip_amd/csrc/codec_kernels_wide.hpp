@@ -18,6 +18,12 @@
 //       exchange between the two lanes (16 DPP moves + 16 v_perm); the remaining four stages stay inside a lane.  The even
 //       lane ends up with planes 0..15, the odd lane with planes 16..31.
 // Each lane compacts its own plane words (32 resp. 16 conditional LDS writes).
+//
+// Reference behaviour restated here (not its structure): load_hypercube + rotate_left_1 (src/ndzip/cuda_codec.inl:30-56,
+// common.hh:436-440), block_transform (cuda_codec.inl:68-126; the per-axis passes are fused into one stencil),
+// complement_negative (common.hh:442-449), write_transposed_chunks = chunk head, BxB bit transpose, zero-word compaction
+// (cuda_codec.inl:185-275; stream layout common.hh:328-366).  Parity: every compress test of tests/test_hip_*.py runs through
+// this mapping for float64; tests/test_wide_mapping_model.py is its executable description on the CPU.
 #pragma once
 
 #include "codec_kernels.hpp"
