@@ -113,7 +113,75 @@ def cpu_baseline(host_grid, dims):
             "compress_GBps": round(sample.nbytes / (t1 - t0) / 1e9, 3),
             "decompress_GBps": round(sample.nbytes / (t2 - t1) / 1e9, 3),
         }
+    if oracle.have_ref() and host_grid.ndim == 3 and host_grid.shape[0] >= 32:
+        try:
+            out["cpu_reference_slabs"] = cpu_reference_slabs(host_grid, cores)
+        except Exception as e:  # a reported extra, never fatal
+            out["cpu_reference_slabs"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
     return out
+
+
+def cpu_reference_slabs(host_grid, cores):
+    """The genuine reference serial compressor (oracle/_ref), one z-slab per thread: what a caller of the reference gets from the
+    host's cores without the reference's OpenMP back-end (which needs Boost and does not build here).  Every slab is an
+    independent ndzip stream of 16 k z-planes; ctypes releases the GIL around the calls; buffers are first touched by the
+    thread that uses them."""
+    import threading
+
+    import numpy as np
+
+    from oracle import oracle
+
+    planes = host_grid.shape[0]
+    threads = max(1, min(cores, planes // 16))
+    per = (planes // threads) // 16 * 16
+    threads = min(threads, planes // per)
+    slabs = [host_grid[i * per: (i + 1) * per] for i in range(threads)]
+    tc = [0.0] * threads
+    td = [0.0] * threads
+    ok = [False] * threads
+    start = threading.Barrier(threads + 1)
+    mid = threading.Barrier(threads + 1)
+    end = threading.Barrier(threads + 1)
+    wdt = np.uint32 if host_grid.itemsize == 4 else np.uint64
+
+    def work(i):
+        local = np.array(slabs[i], copy=True)                 # first touch on this thread
+        oracle.ref_compress(local[:16])                        # warm the code
+        start.wait()
+        t0 = time.perf_counter()
+        s = oracle.ref_compress(local)
+        tc[i] = time.perf_counter() - t0
+        mid.wait()
+        t0 = time.perf_counter()
+        back, _ = oracle.ref_decompress(s, local.dtype, local.shape)
+        td[i] = time.perf_counter() - t0
+        end.wait()
+        ok[i] = bool(np.array_equal(back.view(wdt).reshape(-1), local.view(wdt).reshape(-1)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    mid.wait()
+    t1 = time.perf_counter()
+    end.wait()
+    t2 = time.perf_counter()
+    for t in ts:
+        t.join()
+    nbytes = threads * per * host_grid[0].nbytes
+    return {
+        "value": round(2 * nbytes / (t2 - t0) / 1e9, 3),
+        "unit": "GB/s",
+        "cores": threads,
+        "kind": "reference",
+        "sample": f"{threads} z-slabs of {per} planes ({nbytes >> 20} MiB in all), each compressed and decompressed by the reference's serial CPU "
+                  f"path (oracle/_ref) on its own thread, wall time of the slowest",
+        "compress_GBps": round(nbytes / (t1 - t0) / 1e9, 3),
+        "decompress_GBps": round(nbytes / (t2 - t1) / 1e9, 3),
+        "roundtrip_ok": all(ok),
+    }
 
 
 def main():
