@@ -140,24 +140,29 @@ def cpu_reference_slabs(host_grid, cores):
     tc = [0.0] * threads
     td = [0.0] * threads
     ok = [False] * threads
-    start = threading.Barrier(threads + 1)
-    mid = threading.Barrier(threads + 1)
-    end = threading.Barrier(threads + 1)
+    # (timeouts + abort: a failing worker must not leave the others, or the benchmark, waiting)
+    start = threading.Barrier(threads + 1, timeout=120)
+    mid = threading.Barrier(threads + 1, timeout=120)
+    end = threading.Barrier(threads + 1, timeout=120)
     wdt = np.uint32 if host_grid.itemsize == 4 else np.uint64
 
     def work(i):
-        local = np.array(slabs[i], copy=True)                 # first touch on this thread
-        oracle.ref_compress(local[:16])                        # warm the code
-        start.wait()
-        t0 = time.perf_counter()
-        s = oracle.ref_compress(local)
-        tc[i] = time.perf_counter() - t0
-        mid.wait()
-        t0 = time.perf_counter()
-        back, _ = oracle.ref_decompress(s, local.dtype, local.shape)
-        td[i] = time.perf_counter() - t0
-        end.wait()
-        ok[i] = bool(np.array_equal(back.view(wdt).reshape(-1), local.view(wdt).reshape(-1)))
+        try:
+            local = np.array(slabs[i], copy=True)                 # first touch on this thread
+            oracle.ref_compress(local[:16])                        # warm the code
+            start.wait()
+            t0 = time.perf_counter()
+            s = oracle.ref_compress(local)
+            tc[i] = time.perf_counter() - t0
+            mid.wait()
+            t0 = time.perf_counter()
+            back, _ = oracle.ref_decompress(s, local.dtype, local.shape)
+            td[i] = time.perf_counter() - t0
+            end.wait()
+            ok[i] = bool(np.array_equal(back.view(wdt).reshape(-1), local.view(wdt).reshape(-1)))
+        except Exception:
+            for b in (start, mid, end):
+                b.abort()
 
     ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
     for t in ts:
