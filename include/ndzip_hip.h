@@ -99,7 +99,6 @@ NDZIP_HIP_API int ndzip_hip_compressor_offset_header(ndzip_hip_compressor *c, ui
 NDZIP_HIP_API int ndzip_hip_compressor_offset_header_device(
         ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, const uint32_t *d_base);
 
-/* Reads and clears the handle's sticky device error word; synchronises the handle's stream. */
 /* The same with the base computed on the device from the all-gathered shard lengths: base of shard `rank` = sum over
  * r < rank of (d_lengths[r] - d_borders[r]) (words written by compress_split incl. the shard's border, minus its border
  * words); the base is also stored to *d_base_out (may be NULL) for ndzip_hip_decompressor_decompress_split.  One launch
@@ -107,6 +106,12 @@ NDZIP_HIP_API int ndzip_hip_compressor_offset_header_device(
 NDZIP_HIP_API int ndzip_hip_compressor_offset_header_gathered(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count,
         const uint32_t *d_lengths, const uint32_t *d_borders, uint32_t rank, uint32_t *d_base_out);
 
+/* Reads and clears the handle's sticky device error word; synchronises the handle's stream.  MANDATORY at the caller's
+ * first host synchronisation after a compress call when the stream is going to be kept: a look-back timeout (a device
+ * that made no forward progress for ~0.2 s) leaves a stream whose offsets are wrong.  As a second line of defence such a
+ * launch also stores 0 to *d_stream_length_words -- shorter than any valid stream, so every consumer of the length
+ * (ndzip_hip_stream_words, the decompress entry points) rejects it.  The host-pointer entry points below check for the
+ * caller. */
 NDZIP_HIP_API int ndzip_hip_compressor_check(ndzip_hip_compressor *c);
 
 NDZIP_HIP_API int ndzip_hip_compressor_destroy(ndzip_hip_compressor *c);
@@ -119,6 +124,14 @@ NDZIP_HIP_API int ndzip_hip_decompressor_create(int dtype, int dims, void *hip_s
 NDZIP_HIP_API int ndzip_hip_decompressor_decompress(
         ndzip_hip_decompressor *d, const void *d_stream, void *d_out, int dims, const uint32_t *extent);
 
+/* The same for a caller that knows how many words `d_stream` holds (the reference interface has no such argument and
+ * trusts the header, cuda_codec.inl:628-652): header entries that point outside the stream make the affected hypercubes
+ * decode as zeros and set the error word (ndzip_hip_decompressor_check) instead of reading out of bounds.  Without a
+ * length (the call above) entries are still held to the format's own bounds: offset_after(hc) within
+ * [(hc + 1) * 4096 / B, (hc + 1) * (4096 + 4096 / B)] words. */
+NDZIP_HIP_API int ndzip_hip_decompressor_decompress_bounded(ndzip_hip_decompressor *d, const void *d_stream,
+        uint32_t stream_length_words, void *d_out, int dims, const uint32_t *extent);
+
 /* Split-buffer variant matching ndzip_hip_compressor_compress_split: `d_header` holds this extent's
  * num_hypercubes global offset_after entries; `d_header_base` points to a DEVICE uint32 holding the global
  * offset of `d_body`'s first word (NULL = 0).  For shard r > 0 that is simply the address of the previous
@@ -126,6 +139,11 @@ NDZIP_HIP_API int ndzip_hip_decompressor_decompress(
 NDZIP_HIP_API int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uint32_t *d_header,
         const uint32_t *d_header_base, const void *d_body, void *d_out, int dims, const uint32_t *extent);
 
+/* ... with `body_words` = words `d_body` holds (this shard's hypercube runs + its border) */
+NDZIP_HIP_API int ndzip_hip_decompressor_decompress_split_bounded(ndzip_hip_decompressor *d, const uint32_t *d_header,
+        const uint32_t *d_header_base, const void *d_body, uint32_t body_words, void *d_out, int dims, const uint32_t *extent);
+
+/* Reads and clears the handle's sticky device error word (corrupt header entries); synchronises the handle's stream. */
 NDZIP_HIP_API int ndzip_hip_decompressor_check(ndzip_hip_decompressor *d);
 NDZIP_HIP_API int ndzip_hip_decompressor_destroy(ndzip_hip_decompressor *d);
 
@@ -175,8 +193,10 @@ NDZIP_HIP_API int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uin
 
 /* Words of the stream of an array of `extent` that starts at HOST pointer `stream`: header + last offset + border
  * (what decompress returns, cuda_codec.inl:740-745), from the header alone -- lets a reader split a file of concatenated
- * streams (src/compress/compress.cc:62-86) before decompressing.  `available_words`: how many words `stream` holds;
- * fails with NDZIP_HIP_ERR_INVALID_ARGUMENT if the header itself or the implied stream does not fit. */
+ * streams (src/compress/compress.cc:62-86) before decompressing.  `available_words`: how many words `stream` holds.
+ * Validates the whole header: every entry must follow its predecessor by the length of one encoded hypercube (4096 / B
+ * .. 4096 + 4096 / B words) and the implied stream must fit `available_words`; NDZIP_HIP_ERR_INVALID_ARGUMENT otherwise.
+ * The host-pointer decompress entry points call this first, so a corrupt or truncated stream never reaches the device. */
 NDZIP_HIP_API int ndzip_hip_stream_words(int dtype, int dims, const uint32_t *extent, const void *stream, uint64_t available_words,
         uint32_t *words);
 

@@ -17,7 +17,8 @@ OBJDIR = os.path.join(CSRC, "_build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 SOURCES = ["kernels_f32.hip", "kernels_f64.hip", "capi.hip"]
-HEADERS = ["codec_common.hpp", "codec_kernels.hpp", "codec_launch.hpp", "codec_launch.inl", "../../include/ndzip_hip.h"]
+# every header a translation unit can see: a stale object for the newest kernel is the worst kind of benchmark bug
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inl"))) + ["../../include/ndzip_hip.h"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("NDZIP_EXTRA_FLAGS", "").split()  # experiments only (tools/)
 

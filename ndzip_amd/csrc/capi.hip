@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -37,6 +38,18 @@ int fail_hip(hipError_t e, const char *what) {
         hipError_t e_ = (expr);                                \
         if (e_ != hipSuccess) return fail_hip(e_, #expr);      \
     } while (0)
+
+// NDZIP_VERBOSE (any non-empty value), the reference's only tracing switch (src/ndzip/common.hh:630-633): the device-pointer
+// entry points report the hypercube count when they enqueue (cuda_codec.inl:565-567; nothing is timed there -- they never
+// synchronise), the host-pointer entry points the device pipeline time by events (cuda_codec.inl:688-703, :733-755).
+// Goes to stderr, so a stream written to stdout stays intact.  The ONLY environment variable this library reads.
+bool verbose() {
+    static const bool on = [] {
+        const char *e = getenv("NDZIP_VERBOSE");
+        return e && *e;
+    }();
+    return on;
+}
 
 bool valid_dtype(int dtype) { return dtype == NDZIP_HIP_F32 || dtype == NDZIP_HIP_F64; }
 bool valid_dims(int dims) { return dims >= 1 && dims <= 3; }
@@ -84,8 +97,17 @@ int check_limits(int dtype, const grid_geom &gg) {
 
 template<typename W, bool Pack>
 __global__ void border_kernel(W *data, W *body, const uint32_t *header, uint32_t nhc, const uint32_t *header_base, border_geom bg,
-        uint32_t *out_len, uint32_t len_extra) {
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err, uint32_t body_words) {
     const uint64_t start = nhc ? header[nhc - 1] - (header_base ? *header_base : 0u) : 0u;  // stream<Profile>::border(), common.hh:365
+    if (!Pack) {
+        // unpacking trusts the last header entry only as far as the format allows (same rule as decompress_kernel)
+        constexpr uint64_t B = sizeof(W) * 8;
+        const uint64_t lo = static_cast<uint64_t>(nhc) * (hc_size / B), hi = static_cast<uint64_t>(nhc) * (hc_size / B * (B + 1));
+        if (start < lo || start > hi || start + bg.count > body_words) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, 2u);
+            return;
+        }
+    }
     W *border = body + start;
     const uint64_t zpart = bg.cz * bg.per_z;
     const uint64_t tails = bg.cy * bg.tail;
@@ -135,7 +157,7 @@ __global__ void offset_header_gathered_kernel(uint32_t *header, uint32_t count, 
 
 template<bool Pack>
 hipError_t launch_border(int dtype, void *data, void *body, const uint32_t *header, uint32_t nhc, const uint32_t *header_base,
-        const border_geom &bg, uint32_t *out_len, uint32_t len_extra, hipStream_t stream) {
+        const border_geom &bg, uint32_t *out_len, uint32_t len_extra, hipStream_t stream, uint32_t *err, uint32_t body_words) {
     if (bg.count == 0) {
         if (Pack && out_len && nhc == 0) hipLaunchKernelGGL(store_length_kernel, dim3(1), dim3(1), 0, stream, out_len, len_extra);
         return hipGetLastError();
@@ -144,10 +166,10 @@ hipError_t launch_border(int dtype, void *data, void *body, const uint32_t *head
     if (blocks > 65536) blocks = 65536;
     if (dtype == NDZIP_HIP_F32) {
         hipLaunchKernelGGL((border_kernel<uint32_t, Pack>), dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream,
-                static_cast<uint32_t *>(data), static_cast<uint32_t *>(body), header, nhc, header_base, bg, out_len, len_extra);
+                static_cast<uint32_t *>(data), static_cast<uint32_t *>(body), header, nhc, header_base, bg, out_len, len_extra, err, body_words);
     } else {
         hipLaunchKernelGGL((border_kernel<uint64_t, Pack>), dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream,
-                static_cast<uint64_t *>(data), static_cast<uint64_t *>(body), header, nhc, header_base, bg, out_len, len_extra);
+                static_cast<uint64_t *>(data), static_cast<uint64_t *>(body), header, nhc, header_base, bg, out_len, len_extra, err, body_words);
     }
     return hipGetLastError();
 }
@@ -210,13 +232,17 @@ int ndzip_hip_device_info(char *arch, size_t arch_capacity, int *num_compute_uni
 
 int ndzip_hip_compressed_length_bound(int dtype, int dims, const uint32_t *extent, uint64_t *words) {
     if (!valid_dtype(dtype) || !valid_dims(dims) || !extent || !words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
-    *words = length_bound(dtype, make_geom(dims, extent));
+    const grid_geom gg = make_geom(dims, extent);
+    if (num_elements(gg) > 0xffffffffull) return fail(NDZIP_HIP_ERR_LIMIT, "extent has more than 2^32-1 elements (index_type is uint32_t)");
+    *words = length_bound(dtype, gg);
     return NDZIP_HIP_OK;
 }
 
 int ndzip_hip_num_hypercubes(int dims, const uint32_t *extent, uint32_t *num_hypercubes) {
     if (!valid_dims(dims) || !extent || !num_hypercubes) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
-    *num_hypercubes = make_geom(dims, extent).nhc;
+    const grid_geom gg = make_geom(dims, extent);
+    if (num_elements(gg) > 0xffffffffull) return fail(NDZIP_HIP_ERR_LIMIT, "extent has more than 2^32-1 elements (index_type is uint32_t)");
+    *num_hypercubes = gg.nhc;
     return NDZIP_HIP_OK;
 }
 
@@ -281,10 +307,13 @@ static int compress_common(ndzip_hip_compressor *c, const void *d_in, int dims, 
     a.stream = c->stream;
     a.num_cus = c->num_cus;
     a.aligned = is_aligned(c->dtype, gg, d_in);
+    if (verbose()) fprintf(stderr, "[ndzip-hip] compress: %u hypercubes, %llu border elements\n", gg.nhc,
+            static_cast<unsigned long long>(bg.count));
     if (gg.nhc > 0) {
         HIP_TRY(c->dtype == NDZIP_HIP_F32 ? launch_compress<float>(dims, a) : launch_compress<double>(dims, a));
     }
-    HIP_TRY(launch_border<true>(c->dtype, const_cast<void *>(d_in), d_body, d_header, gg.nhc, nullptr, bg, d_len, len_extra, c->stream));
+    HIP_TRY(launch_border<true>(c->dtype, const_cast<void *>(d_in), d_body, d_header, gg.nhc, nullptr, bg, d_len, len_extra, c->stream,
+            c->err, 0xffffffffu));
     return NDZIP_HIP_OK;
 }
 
@@ -368,8 +397,8 @@ int ndzip_hip_decompressor_create(int dtype, int dims, void *hip_stream, ndzip_h
     return NDZIP_HIP_OK;
 }
 
-int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uint32_t *d_header, const uint32_t *header_base,
-        const void *d_body, void *d_out, int dims, const uint32_t *extent) {
+static int decompress_common(ndzip_hip_decompressor *d, const uint32_t *d_header, const uint32_t *header_base, const void *d_body,
+        uint32_t body_words, void *d_out, int dims, const uint32_t *extent) {
     if (!d || !extent || !d_body) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
     if (dims != d->dims) return fail(NDZIP_HIP_ERR_DIMS_MISMATCH, "data dimensionality does not match decompressor dimensionality");
@@ -386,21 +415,42 @@ int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uin
     a.err = d->err;
     a.stream = d->stream;
     a.aligned = is_aligned(d->dtype, gg, d_out);
+    a.body_words = body_words;
+    if (verbose()) fprintf(stderr, "[ndzip-hip] decompress: %u hypercubes, %llu border elements\n", gg.nhc,
+            static_cast<unsigned long long>(border_count(gg)));
     if (gg.nhc > 0) {
         HIP_TRY(d->dtype == NDZIP_HIP_F32 ? launch_decompress<float>(dims, a) : launch_decompress<double>(dims, a));
     }
     const border_geom bg = make_border_geom(gg);
-    HIP_TRY(launch_border<false>(d->dtype, d_out, const_cast<void *>(d_body), d_header, gg.nhc, header_base, bg, nullptr, 0, d->stream));
+    HIP_TRY(launch_border<false>(d->dtype, d_out, const_cast<void *>(d_body), d_header, gg.nhc, header_base, bg, nullptr, 0, d->stream,
+            d->err, body_words));
     return NDZIP_HIP_OK;
 }
 
+int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor *d, const uint32_t *d_header, const uint32_t *header_base,
+        const void *d_body, void *d_out, int dims, const uint32_t *extent) {
+    return decompress_common(d, d_header, header_base, d_body, 0xffffffffu, d_out, dims, extent);
+}
+
+int ndzip_hip_decompressor_decompress_split_bounded(ndzip_hip_decompressor *d, const uint32_t *d_header, const uint32_t *header_base,
+        const void *d_body, uint32_t body_words, void *d_out, int dims, const uint32_t *extent) {
+    return decompress_common(d, d_header, header_base, d_body, body_words, d_out, dims, extent);
+}
+
 int ndzip_hip_decompressor_decompress(ndzip_hip_decompressor *d, const void *d_stream, void *d_out, int dims, const uint32_t *extent) {
+    return ndzip_hip_decompressor_decompress_bounded(d, d_stream, 0xffffffffu, d_out, dims, extent);
+}
+
+int ndzip_hip_decompressor_decompress_bounded(ndzip_hip_decompressor *d, const void *d_stream, uint32_t stream_length_words, void *d_out,
+        int dims, const uint32_t *extent) {
     if (!d || !extent || !d_stream) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
     const uint32_t nhc = make_geom(dims, extent).nhc;
     const uint32_t hw = header_words_for(d->dtype, nhc);
+    if (stream_length_words < hw) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "stream shorter than its header");
     const void *body = static_cast<const char *>(d_stream) + static_cast<size_t>(hw) * word_bytes(d->dtype);
-    return ndzip_hip_decompressor_decompress_split(d, static_cast<const uint32_t *>(d_stream), nullptr, body, d_out, dims, extent);
+    const uint32_t body_words = stream_length_words == 0xffffffffu ? 0xffffffffu : stream_length_words - hw;
+    return decompress_common(d, static_cast<const uint32_t *>(d_stream), nullptr, body, body_words, d_out, dims, extent);
 }
 
 int ndzip_hip_decompressor_check(ndzip_hip_decompressor *d) {
@@ -453,9 +503,10 @@ int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, cons
     ndzip_hip_compressor *c = nullptr;
     if (int s = ndzip_hip_compressor_create(dtype, dims, gg.nhc, nullptr, &c)) return s;
     event_pair ev;
+    const bool timed = kernel_ns != nullptr || verbose();
     int status = NDZIP_HIP_OK;
     do {
-        if (kernel_ns) {
+        if (timed) {
             if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
                 status = fail(NDZIP_HIP_ERR_RUNTIME, "hipEventCreate failed");
                 break;
@@ -464,12 +515,13 @@ int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, cons
         }
         status = ndzip_hip_compressor_compress(c, d_in.p, dims, extent, d_stream.p, static_cast<uint32_t *>(d_len.p));
         if (status) break;
-        if (kernel_ns) {
+        if (timed) {
             (void) hipEventRecord(ev.stop, nullptr);
             (void) hipEventSynchronize(ev.stop);
             float ms = 0;
             (void) hipEventElapsedTime(&ms, ev.start, ev.stop);
-            *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+            if (kernel_ns) *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+            if (verbose()) fprintf(stderr, "[ndzip-hip][profile] total kernel time %.3fms\n", static_cast<double>(ms));
         }
         status = ndzip_hip_compressor_check(c);
     } while (false);
@@ -492,45 +544,44 @@ int ndzip_hip_offload_decompress(int dtype, int dims, const uint32_t *extent, co
     if (int s = check_limits(dtype, gg)) return s;
     const size_t wb = word_bytes(dtype);
     const size_t out_bytes = num_elements(gg) * wb;
-    // the stream must at least hold its header and the border (reference trusts `length`, cuda_codec.inl:726-730)
-    const uint64_t min_words = header_words_for(dtype, gg.nhc) + static_cast<uint64_t>(gg.nhc) * (hc_size / (wb * 8)) + border_count(gg);
-    if (stream_length_words < min_words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "stream shorter than its header and border");
+    // The reference trusts `length` and the header (cuda_codec.inl:726-730); here the header is checked on the host, where
+    // it already is, so a truncated or corrupt stream is an error code instead of a device fault.
+    uint32_t total_words = 0;
+    if (int s = ndzip_hip_stream_words(dtype, dims, extent, stream, stream_length_words, &total_words)) return s;
     device_buffer d_stream, d_out;
-    HIP_TRY(d_stream.allocate(static_cast<size_t>(stream_length_words) * wb));
+    HIP_TRY(d_stream.allocate(static_cast<size_t>(total_words) * wb));
     HIP_TRY(d_out.allocate(out_bytes));
-    if (stream_length_words) HIP_TRY(hipMemcpy(d_stream.p, stream, static_cast<size_t>(stream_length_words) * wb, hipMemcpyHostToDevice));
+    if (total_words) HIP_TRY(hipMemcpy(d_stream.p, stream, static_cast<size_t>(total_words) * wb, hipMemcpyHostToDevice));
     ndzip_hip_decompressor *d = nullptr;
     if (int s = ndzip_hip_decompressor_create(dtype, dims, nullptr, &d)) return s;
     event_pair ev;
+    const bool timed = kernel_ns != nullptr || verbose();
     int status = NDZIP_HIP_OK;
     do {
-        if (kernel_ns) {
+        if (timed) {
             if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
                 status = fail(NDZIP_HIP_ERR_RUNTIME, "hipEventCreate failed");
                 break;
             }
             (void) hipEventRecord(ev.start, nullptr);
         }
-        status = ndzip_hip_decompressor_decompress(d, d_stream.p, d_out.p, dims, extent);
+        status = ndzip_hip_decompressor_decompress_bounded(d, d_stream.p, total_words, d_out.p, dims, extent);
         if (status) break;
-        if (kernel_ns) {
+        if (timed) {
             (void) hipEventRecord(ev.stop, nullptr);
             (void) hipEventSynchronize(ev.stop);
             float ms = 0;
             (void) hipEventElapsedTime(&ms, ev.start, ev.stop);
-            *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+            if (kernel_ns) *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+            if (verbose()) fprintf(stderr, "[ndzip-hip][profile] total kernel time %.3fms\n", static_cast<double>(ms));
         }
         status = ndzip_hip_decompressor_check(d);
     } while (false);
     ndzip_hip_decompressor_destroy(d);
     if (status) return status;
     if (out_bytes) HIP_TRY(hipMemcpy(data, d_out.p, out_bytes, hipMemcpyDeviceToHost));
-    if (words_consumed) {
-        // border offset + border words, recomputed from the header on the host (cuda_codec.inl:740-745)
-        uint32_t last = 0;
-        if (gg.nhc) last = static_cast<const uint32_t *>(stream)[gg.nhc - 1];
-        *words_consumed = header_words_for(dtype, gg.nhc) + last + static_cast<uint32_t>(border_count(gg));
-    }
+    // border offset + border words, recomputed from the header on the host (cuda_codec.inl:740-745)
+    if (words_consumed) *words_consumed = total_words;
     return NDZIP_HIP_OK;
 }
 
@@ -682,12 +733,25 @@ int ndzip_hip_stream_words(int dtype, int dims, const uint32_t *extent, const vo
     if (num_elements(gg) > 0xffffffffull) return fail(NDZIP_HIP_ERR_LIMIT, "extent has more than 2^32-1 elements (index_type is uint32_t)");
     const uint64_t hw = header_words_for(dtype, gg.nhc);
     if (available_words < hw || (gg.nhc && !stream)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "stream shorter than its header");
-    const uint64_t last = gg.nhc ? static_cast<const uint32_t *>(stream)[gg.nhc - 1] : 0;
-    const uint64_t total = hw + last + border_count(gg);
+    // every entry: offset_after(hc) - offset_after(hc - 1) is the length of one encoded hypercube, head words (4096 / B)
+    // up to head words + 4096 (common.hh:391-392) -- which also makes the entries strictly increasing
     const uint64_t B = dtype == NDZIP_HIP_F32 ? 32 : 64;
-    if (last < static_cast<uint64_t>(gg.nhc) * (hc_size / B) || total > length_bound(dtype, gg) || total > available_words) {
-        return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "header does not describe a stream that fits the given words");
+    const uint64_t min_len = hc_size / B, max_len = hc_size / B * (B + 1);
+    const uint32_t *entries = static_cast<const uint32_t *>(stream);
+    uint64_t last = 0;
+    for (uint32_t hc = 0; hc < gg.nhc; ++hc) {
+        const uint64_t e = entries[hc];
+        if (e < last + min_len || e > last + max_len) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "corrupt stream header: entry %u = %llu after %llu is not one encoded hypercube", hc,
+                    static_cast<unsigned long long>(e), static_cast<unsigned long long>(last));
+            return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, buf);
+        }
+        last = e;
     }
+    const uint64_t total = hw + last + border_count(gg);
+    if (total > 0xffffffffull) return fail(NDZIP_HIP_ERR_LIMIT, "stream length exceeds 2^32-1 words");
+    if (total > available_words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "header describes a stream longer than the given words");
     *words = static_cast<uint32_t>(total);
     return NDZIP_HIP_OK;
 }
@@ -705,7 +769,7 @@ int ndzip_hip_offloader_submit_decompress(ndzip_hip_offloader *o, int slot, cons
     if (out_bytes && !data) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null output");
     if (words) HIP_TRY(hipMemcpyAsync(s->d_stream, stream, static_cast<size_t>(words) * wb, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->start, s->stream));
-    if (int st = ndzip_hip_decompressor_decompress(s->decomp, s->d_stream, s->d_array, o->dims, extent)) return st;
+    if (int st = ndzip_hip_decompressor_decompress_bounded(s->decomp, s->d_stream, words, s->d_array, o->dims, extent)) return st;
     HIP_TRY(hipEventRecord(s->stop, s->stream));
     if (out_bytes) HIP_TRY(hipMemcpyAsync(data, s->d_array, out_bytes, hipMemcpyDeviceToHost, s->stream));
     s->job = 2;
@@ -724,6 +788,11 @@ int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, 
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->start, s->stop));
         *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+    }
+    if (verbose()) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->start, s->stop));
+        fprintf(stderr, "[ndzip-hip][profile] slot %d total kernel time %.3fms\n", slot, static_cast<double>(ms));
     }
     if (job == 1) {
         if (int st = ndzip_hip_compressor_check(s->comp)) return st;

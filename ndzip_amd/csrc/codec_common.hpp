@@ -70,13 +70,17 @@ inline grid_geom make_geom(int dims, const uint32_t *extent) {
     grid_geom gg{};
     gg.dims = static_cast<uint32_t>(dims);
     const uint32_t side = side_for_dims(dims);
-    gg.nhc = 1;
+    uint64_t nhc = 1;
+    bool nhc_overflow = false;
     for (int d = 0; d < max_dims; ++d) {
         gg.n[d] = d < dims ? extent[d] : 1;
         gg.g[d] = d < dims ? extent[d] / side : 1;
         gg.g_magic[d] = gg.g[d] <= 1 ? 0xffffffffu : static_cast<uint32_t>((1ull << 32) / gg.g[d]);
-        if (d < dims) gg.nhc *= gg.g[d];
+        if (d < dims && __builtin_mul_overflow(nhc, static_cast<uint64_t>(gg.g[d]), &nhc)) nhc_overflow = true;
     }
+    // saturates for extents beyond the format's limits (num_elements then exceeds 2^32 - 1 as well: every entry point
+    // rejects such an extent before nhc is used)
+    gg.nhc = nhc_overflow || nhc > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(nhc);
     uint64_t s = 1;
     for (int d = dims - 1; d >= 0; --d) {
         gg.stride[d] = s;
@@ -86,9 +90,12 @@ inline grid_geom make_geom(int dims, const uint32_t *extent) {
     return gg;
 }
 
+// product of the extents, saturating at 2^64 - 1 (three 32-bit extents can exceed 64 bits)
 inline uint64_t num_elements(const grid_geom &gg) {
     uint64_t n = 1;
-    for (uint32_t d = 0; d < gg.dims; ++d) n *= gg.n[d];
+    for (uint32_t d = 0; d < gg.dims; ++d) {
+        if (__builtin_mul_overflow(n, static_cast<uint64_t>(gg.n[d]), &n)) return ~0ull;
+    }
     return n;
 }
 

@@ -44,6 +44,7 @@ struct decompress_args {
     uint32_t *err;
     hipStream_t stream;
     bool aligned;
+    uint32_t body_words;      // words of `body` the caller vouches for (hypercube runs + border); 0xffffffff = unknown
 };
 
 // hypercubes per compress / decompress workgroup for (T, dims)

@@ -93,12 +93,19 @@ NDZIP_DEV uint32_t tile_of_ticket(uint32_t ticket, uint32_t cls, uint32_t num_cl
 
 // tickets[class * ticket_stride_words] = next ticket of the class; tickets[max_ticket_classes * ticket_stride_words] =
 // number of workgroups that have drawn their last ticket
-NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid) {
+// The last workgroup to leave also looks at the error word: a launch that hit a look-back timeout has published offsets
+// that are too small, so its stream is garbage although every write stayed in bounds -- the stream length is then
+// poisoned to 0 (shorter than any valid stream: every consumer of the length fails loudly, ndzip_hip_stream_words and
+// the decompress entry points reject it) for callers that never call ndzip_hip_compressor_check().  The fence orders
+// each workgroup's own out_len / err stores before its 'done' increment.
+NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid, uint32_t *err, uint32_t *out_len) {
     if (tid != 0) return;
     uint32_t *done = tickets + max_ticket_classes * ticket_stride_words;
+    __threadfence();
     if (atomicAdd(done, 1u) == gridDim.x - 1) {
         for (uint32_t c = 0; c < num_classes; ++c) tickets[c * ticket_stride_words] = 0;
         *done = 0;
+        if (out_len && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) *out_len = 0;
     }
 }
 
@@ -113,8 +120,8 @@ NDZIP_DEV uint32_t wave_sum(uint32_t v) {
 // resolves its exclusive prefix by walking back over the predecessors (nearest first, 256 per hop) until a tile
 // with a known inclusive prefix is found.  Forward progress: the grid is persistent and fully resident and every
 // workgroup handles its tiles in increasing order, so the smallest unfinished tile never waits.  Every spin is
-// bounded; on timeout the error word is set and a partial (smaller) sum is returned, which keeps all writes
-// inside the caller's buffer.  While a predecessor is missing only ONE lane polls ONE descriptor (with s_sleep):
+// bounded; on timeout the error word is set and a partial (smaller) sum of PUBLISHED lengths is returned (lanes
+// whose descriptor is unpublished contribute nothing), which keeps all writes inside the caller's buffer.  While a predecessor is missing only ONE lane polls ONE descriptor (with s_sleep):
 // window-wide polling by a thousand workgroups would eat the memory system (MI355X guide, "polling-cost").
 
 NDZIP_DEV void publish_aggregate(desc_ref desc, uint32_t tile, uint32_t aggregate) {
@@ -242,7 +249,11 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
                 break;
             }
         }
-        const bool take = !found || lane <= lf;
+        // After a timeout some lanes still hold UNPUBLISHED descriptors, whose value field is whatever an earlier launch
+        // left there (the scratch is never cleared: epoch tags): those lanes contribute 0, so the prefix returned on a
+        // timeout is a partial sum of real lengths -- never larger than the true prefix, which keeps every write of
+        // this tile inside the caller's buffer.
+        const bool take = (!found || lane <= lf) && desc_state(d, desc.epoch) != 0;
         exclusive += wave_sum(take ? static_cast<uint32_t>(d) : 0u);
         if (found || timed_out) break;
         if (hop_count) ++*hop_count;
@@ -468,7 +479,7 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
     }
     // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
     // visible); the descriptors need no clearing (epoch).
-    release_tickets(tickets, num_classes, tid);
+    release_tickets(tickets, num_classes, tid, err, out_len);
 #undef NDZIP_PHASE
 #ifdef NDZIP_EXP_PHASE_TIMING
     if (timing && tid == 0) {
@@ -725,7 +736,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     }
     // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
     // visible); the descriptors need no clearing (epoch).
-    release_tickets(tickets, num_classes, tid);
+    release_tickets(tickets, num_classes, tid, err, out_len);
 #undef NDZIP_PHASE
 #ifdef NDZIP_EXP_PHASE_TIMING
     if (timing && tid == 0) {
@@ -868,13 +879,13 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         prev_held = E::hold(t, head_a, head_b, E::head_words + chunk_excl);
         tile = next_tile;
     }
-    release_tickets(tickets, num_classes, tid);
+    release_tickets(tickets, num_classes, tid, err, out_len);
 }
 
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads))
 decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restrict__ header_base_ptr, const typename word_of<T>::type *__restrict__ body,
-        typename word_of<T>::type *__restrict__ out, const grid_geom gg, uint32_t *err) {
+        typename word_of<T>::type *__restrict__ out, const grid_geom gg, uint32_t *err, const uint32_t body_words) {
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -903,7 +914,14 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
         const uint32_t header_base = header_base_ptr ? *header_base_ptr : 0u;
         begin = (hc ? header[hc - 1] : header_base) - header_base;  // stream<Profile>::hypercube, common.hh:350-358
         len = header[hc] - header_base - begin;
-        if (len < static_cast<uint32_t>(P::head_words) || len > static_cast<uint32_t>(P::max_hc_words)) {
+        // A header entry is trusted only as far as the format allows: every hypercube takes head_words..max_hc_words
+        // words, so offset_after(hc - 1) lies in [hc * head_words, hc * max_hc_words], and the run must end inside the
+        // body the caller vouched for (body_words; 0xffffffff = unknown, then the format bound is all there is).  A
+        // corrupt entry makes this hypercube decode as zeros and sets the error word instead of reading wherever
+        // `body + begin` points.
+        const uint64_t lo = static_cast<uint64_t>(hc) * P::head_words, hi = static_cast<uint64_t>(hc) * P::max_hc_words;
+        if (len < static_cast<uint32_t>(P::head_words) || len > static_cast<uint32_t>(P::max_hc_words) || begin < lo || begin > hi
+                || static_cast<uint64_t>(begin) + len > body_words) {
             if (t == 0) atomicOr(err, 2u);  // corrupt header
             len = 0;
         }
@@ -1119,7 +1137,7 @@ hipError_t launch_decompress_profile(const decompress_args &a) {
     if (ntiles == 0) return hipSuccess;
     const uint32_t grid = (ntiles + 7) / 8 * 8;  // see the kernel: tiles are dealt to XCDs in contiguous ranges
     hipLaunchKernelGGL((decompress_kernel<T, Dims, Aligned>), dim3(grid), dim3(C::threads), C::smem_bytes, a.stream,
-            a.header, a.header_base, static_cast<const W *>(a.body), static_cast<W *>(a.out), a.gg, a.err);
+            a.header, a.header_base, static_cast<const W *>(a.body), static_cast<W *>(a.out), a.gg, a.err, a.body_words);
     return hipGetLastError();
 }
 

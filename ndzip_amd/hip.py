@@ -57,7 +57,9 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_compressor_destroy",
     "ndzip_hip_decompressor_create",
     "ndzip_hip_decompressor_decompress",
+    "ndzip_hip_decompressor_decompress_bounded",
     "ndzip_hip_decompressor_decompress_split",
+    "ndzip_hip_decompressor_decompress_split_bounded",
     "ndzip_hip_decompressor_check",
     "ndzip_hip_decompressor_destroy",
     "ndzip_hip_offload_compress",
@@ -112,6 +114,8 @@ def lib():
     L.ndzip_hip_decompressor_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.ndzip_hip_decompressor_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _U32P]
     L.ndzip_hip_decompressor_decompress_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _U32P]
+    L.ndzip_hip_decompressor_decompress_bounded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, _U32P]
+    L.ndzip_hip_decompressor_decompress_split_bounded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, _U32P]
     L.ndzip_hip_decompressor_check.argtypes = [C.c_void_p]
     L.ndzip_hip_decompressor_destroy.argtypes = [C.c_void_p]
     L.ndzip_hip_offload_compress.argtypes = [C.c_int, C.c_int, _U32P, C.c_void_p, C.c_void_p, _U32P, C.POINTER(C.c_uint64)]
@@ -269,12 +273,23 @@ class HipDecompressor:
         _check(lib().ndzip_hip_decompressor_create(self.code, dims, C.c_void_p(stream or None), C.byref(h)))
         self._h = h
 
-    def decompress(self, in_device_stream, out_device_data, extent) -> None:
-        _check(lib().ndzip_hip_decompressor_decompress(self._h, _ptr(in_device_stream), _ptr(out_device_data), len(extent), _ext(extent)))
+    def decompress(self, in_device_stream, out_device_data, extent, stream_length_words: Optional[int] = None) -> None:
+        """`stream_length_words` (not part of the reference interface): words the device stream holds; header entries that
+        point past it are rejected on the device (error word) instead of being followed."""
+        if stream_length_words is None:
+            _check(lib().ndzip_hip_decompressor_decompress(self._h, _ptr(in_device_stream), _ptr(out_device_data), len(extent), _ext(extent)))
+        else:
+            _check(lib().ndzip_hip_decompressor_decompress_bounded(self._h, _ptr(in_device_stream), int(stream_length_words),
+                                                                   _ptr(out_device_data), len(extent), _ext(extent)))
 
-    def decompress_split(self, device_header, device_header_base, device_body, out_device_data, extent) -> None:
-        _check(lib().ndzip_hip_decompressor_decompress_split(self._h, _ptr(device_header), _ptr(device_header_base), _ptr(device_body),
-                                                              _ptr(out_device_data), len(extent), _ext(extent)))
+    def decompress_split(self, device_header, device_header_base, device_body, out_device_data, extent, body_words: Optional[int] = None) -> None:
+        if body_words is None:
+            _check(lib().ndzip_hip_decompressor_decompress_split(self._h, _ptr(device_header), _ptr(device_header_base), _ptr(device_body),
+                                                                  _ptr(out_device_data), len(extent), _ext(extent)))
+        else:
+            _check(lib().ndzip_hip_decompressor_decompress_split_bounded(self._h, _ptr(device_header), _ptr(device_header_base),
+                                                                         _ptr(device_body), int(body_words), _ptr(out_device_data),
+                                                                         len(extent), _ext(extent)))
 
     def check(self) -> None:
         _check(lib().ndzip_hip_decompressor_check(self._h))
