@@ -24,10 +24,9 @@
 #include <hip/hip_runtime.h>
 
 #include "codec_common.hpp"
+#include "gfx950_lds.hpp"
 
 namespace ndzip_hip {
-
-#define NDZIP_DEV __device__ __forceinline__
 
 // ---------------------------------------------------------------------------------------------------------
 // small bit helpers (common.hh:436-449)
@@ -120,32 +119,6 @@ struct lds_layout {
     NDZIP_DEV static constexpr uint32_t off(uint32_t k) { return k * static_cast<uint32_t>(sizeof(W)) + (k >> 5) * 16u; }
 };
 
-struct alignas(16) vec16 {
-    uint32_t w[4];
-};
-
-// 16 bytes per lane from LDS in one ds_read_b128.  Ground truth on gfx950 (tools/ldsbench2.hip, inline-asm reads,
-// SQ_LDS_IDX_ACTIVE per wave-instruction): ds_read_b128 at 16-byte-aligned lane strides of 16 / 144 / 272 bytes = 4
-// (the peak: 16 lanes x 16 bytes per count), the equivalent ds_read2_b64 = 16, ds_read_b128 at an address that is
-// only 8-byte aligned = 64.  A b128 access is served in groups of 16 consecutive lanes over sixteen 16-byte slots
-// (address / 16 mod 16); two lanes of a group in the same slot at different addresses double the group's cost.
-NDZIP_DEV vec16 lds_read16(const char *p) {
-    // The address goes through an empty volatile asm: it pins the order of the reads (hipcc otherwise hoists all 24
-    // stencil reads to the top and the kernel spills -- a scratch reload waits vmcnt(0), i.e. for every prefetch load
-    // in flight); the address-space cast keeps it a ds_ access.
-    using lds_char = const __attribute__((address_space(3))) char;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    using lds_vec = const __attribute__((address_space(3))) u32x4;
-    uint32_t a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_char *) p));
-    asm volatile("" : "+v"(a));
-    const u32x4 q = *reinterpret_cast<lds_vec *>(static_cast<uintptr_t>(a));
-    vec16 v;
-    v.w[0] = q.x;
-    v.w[1] = q.y;
-    v.w[2] = q.z;
-    v.w[3] = q.w;
-    return v;
-}
 NDZIP_DEV void lds_write16(char *p, vec16 v) { *reinterpret_cast<vec16 *>(p) = v; }
 
 // 16 / 8 bytes per lane from / to GLOBAL memory.  Aligned = the address is a multiple of the access size; otherwise only

@@ -357,7 +357,7 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
     char *cube = smem + grp * C::cube_stride;       // staging of this group's hypercube
     char *zero_region = smem + K * C::cube_stride;
     char *zero = zero_region + L::template zero_offset<Dims>();
-    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);              // the K encoded runs, back to back
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
@@ -365,9 +365,9 @@ compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geo
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
-    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
+    if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);  // (own slot: see compress_kernel_db)
     __syncthreads();  // (also orders the zero block before the first stencil read)
-    uint32_t tile = tile_of_ticket(misc[NW + 1], cls, num_classes);
+    uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
 
 #ifdef NDZIP_EXP_PHASE_TIMING
     const bool timing = (exp_flags & 16u) != 0;
@@ -542,7 +542,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);             // later: the K encoded runs, back to back
     char *zero_region = smem + K * C::cube_stride;
     char *zero = zero_region + L::template zero_offset<Dims>();
-    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
     stagger_start(exp_flags >> 8);
@@ -550,9 +550,11 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
-    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
+    // The first ticket has its own LDS slot: work-item 0 stores the NEXT ticket to misc[NW + 1] before the loop's first
+    // barrier, and nothing orders that store after the other wavefronts' read of the first one.
+    if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
-    uint32_t tile = tile_of_ticket(misc[NW + 1], cls, num_classes);
+    uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
 
 #ifdef NDZIP_EXP_PHASE_TIMING
     const bool timing = (exp_flags & 16u) != 0;
@@ -786,16 +788,18 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     uint32_t *run32 = reinterpret_cast<uint32_t *>(smem);  // later: the encoded run (f64: as uint32 halves of its words)
     char *zero_region = smem + L::cube_bytes;
     char *zero = zero_region + L::zero_offset;
-    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] ticket
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
 
     const uint32_t ntiles = gg.nhc;
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
-    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
+    // The first ticket has its own LDS slot: work-item 0 stores the NEXT ticket to misc[NW + 1] before the loop's first
+    // barrier, and nothing orders that store after the other wavefronts' read of the first one.
+    if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
-    uint32_t tile = tile_of_ticket(misc[NW + 1], cls, num_classes);
+    uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
 
     wide::input_regs<W> pre;
     wide::load_regs<W, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, tile < ntiles ? tile : ntiles - 1), t, pre);

@@ -97,7 +97,12 @@ def lib():
         import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
     except Exception:  # pragma: no cover - torch-less deployment uses the system runtime
         pass
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def _bind(L):
+    """Declare the argument types of every entry point of include/ndzip_hip.h on a loaded library."""
     L.ndzip_hip_last_error.restype = C.c_char_p
     L.ndzip_hip_device_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
     L.ndzip_hip_compressed_length_bound.argtypes = [C.c_int, C.c_int, _U32P, C.POINTER(C.c_uint64)]
@@ -132,7 +137,6 @@ def lib():
     for name in EXPORTED_SYMBOLS:
         if name != "ndzip_hip_last_error":
             getattr(L, name).restype = C.c_int
-    _lib = L
     return L
 
 

@@ -1,0 +1,196 @@
+"""The HIP kernels, executed work-item by work-item on the CPU (tests/wavesim: a wave64 functional model that compiles the
+product's kernel sources unchanged), against the oracle and the reference-generated golden fixtures -- bit-exact.
+
+This is NOT the GPU parity run (tests/test_hip_*.py, -m gpu, are) and nothing here is a product path: it lets the
+GPU-less authoring container check the kernels' LOGIC -- stencil, bit transposes, plane compaction, chunk scans, the
+ticket / decoupled look-back protocol between concurrently running workgroups, header and border handling -- after every
+kernel edit.  What it cannot check (timing, bank conflicts, cross-XCD coherence) is what the GPU suite and profiles/ are
+for.  Cases mirror src/test/codec_profile_test.inl:37-140, :952-1082 at sizes the model runs in seconds."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ndzip_amd import hip
+from ndzip_amd.synth import synth_numpy
+from oracle import oracle
+from tests.util import PROFILES, SIDE, profile_id, random_bits, random_unit_floats, same_bits
+from tests.wavesim import sim
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+with open(os.path.join(GOLDEN, "hashes.json")) as f:
+    META = json.load(f)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _model():
+    sim.load()
+
+
+def _check(data, **kw):
+    want = oracle.compress(data)
+    got = sim.compress(data, **kw)
+    assert len(got) == len(want), (len(got), len(want))
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, f"first differing words {bad[:8]}"
+    back = sim.decompress(want, data.dtype, data.shape)
+    assert same_bits(back, data)
+    return got
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_single_hypercube(profile):
+    dtype, dims = profile
+    _check(random_unit_floats((SIDE[dims],) * dims, dtype, 22))
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+@pytest.mark.parametrize("n", [0, 1])
+def test_zero_hypercubes(profile, n):
+    dtype, dims = profile
+    data = np.full((n,) * dims, 42, dtype=dtype)
+    assert len(_check(data)) == n
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+@pytest.mark.parametrize("kind", ["bits", "unit", "synthetic", "zeros"])
+def test_many_hypercubes_aligned_and_with_border(profile, kind):
+    dtype, dims = profile
+    side = SIDE[dims]
+    shapes = {1: [(side * 9,), (side * 3 + 17,)], 2: [(side * 3, side * 4), (side * 2 + 1, side * 3 + 3)],
+              3: [(side * 2, side * 3, side * 4), (side * 2 + 5, side + 1, side * 3 + 2)]}[dims]
+    for i, shape in enumerate(shapes):
+        if kind == "bits":
+            data = random_bits(shape, dtype, 30 + i)
+        elif kind == "unit":
+            data = random_unit_floats(shape, dtype, 40 + i)
+        elif kind == "zeros":
+            data = np.zeros(shape, dtype)
+            data.reshape(-1)[::977] = -0.0
+        else:
+            data = synth_numpy(shape, dtype, seed=50 + i, noise_mask=0xFF)
+        _check(data)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_more_workgroups_than_tiles_and_many_resident(profile):
+    """The ticket / look-back protocol with 12 concurrently resident workgroups (and with a grid larger than the work)."""
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 40,), 2: (side * 6, side * 7), 3: (side * 3, side * 4, side * 4)}[dims]
+    data = synth_numpy(shape, dtype, seed=5, noise_mask=0xFFF)
+    _check(data, cus=4, blocks_per_cu=3)
+    small = {1: (side * 2,), 2: (side, side * 3), 3: (side, side, side * 2)}[dims]
+    _check(synth_numpy(small, dtype, seed=6, noise_mask=0xFF), cus=4, blocks_per_cu=3)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_one_resident_workgroup(profile):
+    """A grid of one persistent workgroup walks every tile itself (every look-back finds its own previous tile)."""
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 5,), 2: (side * 2, side * 3), 3: (side, side * 2, side * 3)}[dims]
+    _check(random_unit_floats(shape, dtype, 3), cus=1, blocks_per_cu=1)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+@pytest.mark.parametrize("skew", [1, 3])
+def test_element_aligned_pointers(profile, skew):
+    """Array and stream pointers that are only element-aligned: the 16-byte accesses of the kernels assume no more."""
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 3 + 5,), 2: (side * 2 + 3, side * 3), 3: (side * 2, side + 3, side * 2 + 1)}[dims]
+    data = synth_numpy(shape, dtype, seed=77 + skew, noise_mask=0xFF)
+    holder = np.zeros(data.size + 8, dtype=dtype)
+    view = holder[skew: skew + data.size].reshape(shape)
+    view[...] = data
+    want = oracle.compress(data)
+    got = sim.compress(view, misalign_words=skew)
+    assert np.array_equal(got, want)
+
+
+def test_f64_odd_hypercube_count_zeroes_header_pad():
+    data = np.zeros(3 * 4096, dtype=np.float64)
+    s = _check(data)
+    assert len(s) == 194 and s[0] == 0x0000008000000040 and s[1] == 0x00000000000000C0
+    s2 = _check(random_unit_floats((200, 70), np.float64, 7))  # NHC = 3
+    assert np.frombuffer(s2.tobytes(), dtype=np.uint32)[3] == 0
+
+
+def test_known_answers_from_reference():
+    """Known answers captured from the compiled reference."""
+    s = sim.compress(np.zeros(4096, np.float32))
+    assert len(s) == 129 and s[0] == 0x80 and not s[1:].any()
+    s = sim.compress(np.ones(4096, np.float32))
+    assert len(s) == 136 and s[0] == 0x87 and s[1] == 0x7F000000 and not s[2:129].any() and (s[129:] == 0x80000000).all()
+    s = sim.compress(np.ones(4096, np.float64))
+    assert len(s) == 75 and s[0] == 0x4A and s[1] == 0x7FE0000000000000 and (s[65:] == 0x8000000000000000).all()
+    b = np.zeros(4099, np.float32)
+    b[4096:] = [1, 2, -1]
+    s = sim.compress(b)
+    assert len(s) == 132 and list(s[-3:]) == [0x3F800000, 0x40000000, 0xBF800000]
+
+
+@pytest.mark.parametrize("case", META["small_cases"], ids=lambda c: c["name"])
+def test_reference_streams(case):
+    """Byte-exact (input, stream) pairs produced by the compiled reference (tests/golden/make_golden.py)."""
+    vec = np.load(os.path.join(GOLDEN, "vectors.npz"))
+    data, want = vec[case["name"] + "__in"], vec[case["name"] + "__stream"]
+    got = sim.compress(data)
+    assert len(got) == len(want) and np.array_equal(got, want)
+    assert same_bits(sim.decompress(want, data.dtype, data.shape), data)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_corrupt_header_entries_are_contained(profile):
+    """A header entry that points outside the stream: the affected hypercubes decode as zeros and the error word is set
+    (NDZIP_HIP_ERR_DEVICE_FAULT from check()) -- the model would crash on a wild read just like the device."""
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 4,), 2: (side * 2, side * 2), 3: (side, side * 2, side * 2)}[dims]
+    data = random_unit_floats(shape, dtype, 9)
+    stream = oracle.compress(data).copy()
+    header = stream[: 2 if np.dtype(dtype).itemsize == 8 else 4].view(np.uint32)
+    header[1] = 0xFFFFFF00
+    with pytest.raises(hip.NdzipHipError, match="corrupt stream header"):
+        sim.decompress(stream, dtype, shape, bounded=True)
+    with pytest.raises(hip.NdzipHipError, match="corrupt stream header"):
+        sim.decompress(stream, dtype, shape, bounded=False)
+    # a plausible length but an offset past the words the caller vouched for
+    stream2 = oracle.compress(data)
+    with pytest.raises(hip.NdzipHipError, match="corrupt stream header"):
+        with sim.active():
+            dec = hip.make_hip_decompressor(dtype, dims)
+            out = np.zeros(shape, dtype)
+            dec.decompress(stream2.ctypes.data, out.ctypes.data, shape, stream_length_words=len(stream2) - 40)
+            dec.check()
+
+
+@pytest.mark.parametrize("profile", [(np.float32, 3), (np.float64, 2)], ids=profile_id)
+def test_host_pointer_offloader_and_pipelined_offloader(profile):
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {2: (side * 2 + 5, side * 3), 3: (side * 2, side * 2 + 3, side * 2)}[dims]
+    data = random_unit_floats(shape, dtype, 60)
+    want = oracle.compress(data)
+    with sim.active():
+        off = hip.make_hip_offloader(dtype, dims)
+        stream = off.compress(data)
+        assert np.array_equal(stream, want)
+        back, consumed = off.decompress(stream, shape)
+        assert consumed == len(stream) and same_bits(back, data)
+        with pytest.raises(hip.NdzipHipError, match="corrupt stream header|longer than the given words|shorter"):
+            off.decompress(stream[:-3], shape)
+        po = hip.HipPipelinedOffloader(dtype, shape, slots=2)
+        outs = [np.zeros(hip.compressed_length_bound(dtype, shape), dtype=want.dtype) for _ in range(2)]
+        po.submit_compress(0, data, outs[0])
+        po.submit_compress(1, data, outs[1])
+        for slot in (0, 1):
+            words, _ = po.wait(slot)
+            assert words == len(want) and np.array_equal(outs[slot][:words], want)
+        back2 = np.zeros(shape, dtype)
+        po.submit_decompress(0, want, back2)
+        words, _ = po.wait(0)
+        assert words == len(want) and same_bits(back2, data)
+        po.close()

@@ -1,0 +1,69 @@
+"""TEST INFRASTRUCTURE ONLY: builds tests/wavesim/libndzip_hip_wavesim.so -- the product's kernel and C-ABI sources
+(ndzip_amd/csrc/*.hip, *.inl, *.hpp, unchanged) compiled as host C++ against the wave64 functional model in this directory
+(hip/hip_runtime.h, wavesim.cc).  The one product header that is substituted is gfx950_lds.hpp (a VGPR-pinned LDS address).
+
+Nothing under ndzip_amd/ imports or loads this; tests/test_wavesim_*.py do.  `python -m tests.wavesim.build`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "ndzip_amd", "csrc")
+OUT = os.path.join(HERE, "libndzip_hip_wavesim.so")
+BUILD = os.path.join(HERE, "_build")
+CXX = os.environ.get("WAVESIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+FLAGS = ["-std=c++17", "-O1", "-g0", "-fPIC", "-pthread", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unknown-attributes",
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-const-variable"]
+FLAGS += os.environ.get("WAVESIM_EXTRA_FLAGS", "").split()
+UNITS = ["kernels_f32.hip", "kernels_f64.hip", "capi.hip"]
+
+
+def _sources():
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".inl"))]
+    files += [os.path.join(ROOT, "include", "ndzip_hip.h")]
+    files += [os.path.join(HERE, f) for f in ("gfx950_lds.hpp", "wavesim.cc", os.path.join("hip", "hip_runtime.h"), "build.py")]
+    return files
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in _sources()):
+        return OUT
+    # mirror the product tree so that its relative includes resolve, with the one substituted header
+    src = os.path.join(BUILD, "ndzip_amd", "csrc")
+    shutil.rmtree(BUILD, ignore_errors=True)
+    os.makedirs(src)
+    os.makedirs(os.path.join(BUILD, "include"))
+    for f in os.listdir(CSRC):
+        if f.endswith((".hip", ".hpp", ".inl")):
+            shutil.copy(os.path.join(CSRC, f), os.path.join(src, f))
+    shutil.copy(os.path.join(HERE, "gfx950_lds.hpp"), os.path.join(src, "gfx950_lds.hpp"))
+    shutil.copy(os.path.join(ROOT, "include", "ndzip_hip.h"), os.path.join(BUILD, "include", "ndzip_hip.h"))
+
+    def compile_one(job):
+        source, obj = job
+        cmd = [CXX, *FLAGS, "-x", "c++", "-I", HERE, "-c", source, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"wavesim build failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    jobs = [(os.path.join(src, u), os.path.join(BUILD, u.replace(".hip", ".o"))) for u in UNITS]
+    jobs.append((os.path.join(HERE, "wavesim.cc"), os.path.join(BUILD, "wavesim.o")))
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        objs = list(ex.map(compile_one, jobs))
+    cmd = [CXX, "-shared", "-fPIC", "-pthread", "-o", OUT, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"wavesim link failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,29 @@
+// tests/wavesim/gfx950_lds.hpp -- TEST INFRASTRUCTURE ONLY: the wave64 functional model's stand-in for
+// ndzip_amd/csrc/gfx950_lds.hpp (the only product header it does not compile as is): the same 16-byte LDS read without the
+// VGPR-pinned 32-bit LDS address, which has no meaning on the host.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+namespace ndzip_hip {
+
+#define NDZIP_DEV __device__ __forceinline__
+
+struct alignas(16) vec16 {
+    uint32_t w[4];
+};
+
+NDZIP_DEV vec16 lds_read16(const char *p) {
+    if (reinterpret_cast<uintptr_t>(p) % 16 != 0) {  // a misaligned ds_read_b128 is a kernel bug (and 16x slower on gfx950)
+        fprintf(stderr, "wavesim: lds_read16 at a misaligned address\n");
+        abort();
+    }
+    vec16 v;
+    std::memcpy(&v, p, sizeof v);
+    return v;
+}
+
+}  // namespace ndzip_hip

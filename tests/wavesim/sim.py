@@ -1,0 +1,77 @@
+"""TEST INFRASTRUCTURE ONLY: loads the wave64 functional model of the HIP library (tests/wavesim/build.py) and drives it
+through the very same C ABI bindings as the real library (ndzip_amd.hip._bind); "device pointers" are numpy buffers."""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+import os
+
+import numpy as np
+
+from ndzip_amd import hip
+
+from . import build as simbuild
+
+_sim = None
+
+
+def load():
+    global _sim
+    if _sim is None:
+        _sim = hip._bind(C.CDLL(simbuild.build()))
+    return _sim
+
+
+@contextlib.contextmanager
+def active(cus: int = 2, blocks_per_cu: int = 2):
+    """Route ndzip_amd.hip's ctypes calls to the model for the duration of the block (tests only: the product never does)."""
+    L = load()
+    saved, env = hip._lib, {k: os.environ.get(k) for k in ("WAVESIM_CUS", "WAVESIM_BLOCKS_PER_CU")}
+    os.environ["WAVESIM_CUS"] = str(cus)
+    os.environ["WAVESIM_BLOCKS_PER_CU"] = str(blocks_per_cu)
+    hip._lib = L
+    try:
+        yield L
+    finally:
+        hip._lib = saved
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _words(dtype):
+    return np.uint32 if np.dtype(dtype).itemsize == 4 else np.uint64
+
+
+def compress(data: np.ndarray, cus: int = 2, blocks_per_cu: int = 2, misalign_words: int = 0) -> np.ndarray:
+    """Device-pointer compress (ndzip_hip_compressor_compress) on the model; returns the stream words."""
+    data = np.ascontiguousarray(data)
+    with active(cus, blocks_per_cu):
+        bound = hip.compressed_length_bound(data.dtype, data.shape)
+        out = np.zeros(max(1, bound) + 8, dtype=_words(data.dtype))
+        length = np.zeros(1, dtype=np.uint32)
+        comp = hip.make_hip_compressor(data.dtype, hip.CompressorRequirements(data.shape))
+        try:
+            comp.compress(data.ctypes.data, data.shape, out.ctypes.data + misalign_words * out.itemsize, length.ctypes.data)
+            comp.check()
+        finally:
+            comp.close()
+    n = int(length[0])
+    assert n <= bound
+    return out[misalign_words:misalign_words + n].copy()
+
+
+def decompress(stream: np.ndarray, dtype, extent, bounded: bool = False) -> np.ndarray:
+    stream = np.ascontiguousarray(stream)
+    out = np.zeros(extent, dtype=dtype)
+    with active():
+        dec = hip.make_hip_decompressor(dtype, len(extent))
+        try:
+            buf = stream if stream.size else np.zeros(1, dtype=_words(dtype))
+            dec.decompress(buf.ctypes.data, out.ctypes.data, extent, stream.size if bounded else None)
+            dec.check()
+        finally:
+            dec.close()
+    return out

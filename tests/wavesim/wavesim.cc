@@ -1,0 +1,347 @@
+// tests/wavesim/wavesim.cc -- TEST INFRASTRUCTURE ONLY: scheduler of the wave64 functional model (see hip/hip_runtime.h).
+//
+// A workgroup runs on one OS thread; its work-items are fibers switched cooperatively at the only points where work-items
+// can observe each other: __syncthreads, wave-wide operations (shuffle / ballot / DPP rendezvous all 64 lanes of a
+// wavefront) and s_sleep.  Up to WAVESIM_MAX_RESIDENT workgroups are resident at a time and are started in blockIdx
+// order, like a hardware dispatcher with that many slots -- a persistent kernel whose grid fits is fully co-resident, and
+// its inter-workgroup protocol (tickets, decoupled look-back over global memory) runs with real concurrency.
+//
+// The model aborts with a diagnostic on what would hang or be undefined on hardware: a barrier or wave operation that
+// can never complete (divergent __syncthreads), lanes of one wavefront meeting in different wave operations.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <sys/mman.h>
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+namespace wavesim {
+
+namespace {
+
+constexpr size_t stack_bytes = 256 * 1024;
+
+// ---- minimal x86-64 context switch (callee-saved registers + stack pointer) ---------------------------------------------
+extern "C" void wavesim_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl wavesim_switch
+.hidden wavesim_switch
+.type wavesim_switch,@function
+wavesim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size wavesim_switch,.-wavesim_switch
+)");
+
+struct wg_state;
+
+enum op_tag : unsigned { op_none = 0, op_exchange = 1, op_ballot = 2, op_dpp = 3 };
+
+struct wave_state {
+    uint64_t slot[2][64];
+    unsigned arrived = 0;
+    unsigned gen = 0;  // completed rendezvous
+    unsigned alive = 64;
+    unsigned tag = op_none;
+};
+
+}  // namespace
+
+struct lane_ctx {
+    void *sp = nullptr;
+    void *stack = nullptr;
+    wg_state *wg = nullptr;
+    unsigned tid = 0;
+    bool done = false;
+    const unsigned *wait_on = nullptr;  // blocked while *wait_on == wait_val
+    unsigned wait_val = 0;
+    const char *where = "";             // what the work-item waits in (deadlock report)
+    void *site = nullptr;               // return address of that call
+};
+
+namespace {
+
+struct wg_state {
+    unsigned block_idx = 0, block_dim = 0, grid_dim = 0;
+    std::vector<lane_ctx> lanes;
+    std::vector<wave_state> waves;
+    unsigned barrier_arrived = 0, barrier_gen = 0, alive = 0;
+    void *sched_sp = nullptr;
+    void (*fn)(void *) = nullptr;
+    void *arg = nullptr;
+};
+
+thread_local lane_ctx *g_self = nullptr;
+
+[[noreturn]] void die(const char *what) {
+    fprintf(stderr, "wavesim: %s\n", what);
+    abort();
+}
+
+void yield_to_scheduler() {
+    lane_ctx *l = g_self;
+    wavesim_switch(&l->sp, l->wg->sched_sp);
+}
+
+void release_if_complete(wg_state *wg, wave_state *w) {
+    if (w && w->alive > 0 && w->arrived == w->alive) {
+        w->arrived = 0;
+        w->tag = op_none;
+        ++w->gen;
+    }
+    if (wg->alive > 0 && wg->barrier_arrived == wg->alive) {
+        wg->barrier_arrived = 0;
+        ++wg->barrier_gen;
+    }
+}
+
+void lane_entry() {
+    lane_ctx *l = g_self;
+    wg_state *wg = l->wg;
+    wg->fn(wg->arg);
+    // the work-item has ended: barriers and wave operations no longer wait for it (hardware counts live waves / EXEC)
+    l = g_self;
+    l->done = true;
+    wave_state *w = &wg->waves[l->tid / 64];
+    --w->alive;
+    --wg->alive;
+    release_if_complete(wg, w);
+    void *dummy;
+    wavesim_switch(&dummy, wg->sched_sp);
+    die("a finished work-item was resumed");
+}
+
+void prepare_fiber(lane_ctx &l) {
+    // stack as wavesim_switch expects it: six callee-saved registers, then the address `ret` jumps to; the slot above it
+    // plays the return address of lane_entry, which leaves rsp = 8 mod 16 at its first instruction as the ABI requires
+    uintptr_t top = reinterpret_cast<uintptr_t>(l.stack) + stack_bytes;
+    top &= ~static_cast<uintptr_t>(15);
+    void **sp = reinterpret_cast<void **>(top);
+    *--sp = nullptr;                                  // fake return address of lane_entry
+    *--sp = reinterpret_cast<void *>(&lane_entry);    // ret target
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;      // rbp rbx r12 r13 r14 r15
+    l.sp = sp;
+}
+
+struct thread_stacks {
+    std::vector<void *> stacks;
+    ~thread_stacks() {
+        for (void *s : stacks) munmap(s, stack_bytes);
+    }
+    void *get(size_t i) {
+        while (stacks.size() <= i) {
+            void *p = mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (p == MAP_FAILED) die("cannot map a fiber stack");
+            stacks.push_back(p);
+        }
+        return stacks[i];
+    }
+};
+
+void run_workgroup(unsigned block_idx, launch_cfg cfg, void (*fn)(void *), void *arg, thread_stacks &stacks) {
+    if (cfg.block == 0 || cfg.block > 1024) die("block size must be 1..1024");
+    wg_state wg;
+    wg.block_idx = block_idx;
+    wg.block_dim = cfg.block;
+    wg.grid_dim = cfg.grid;
+    wg.fn = fn;
+    wg.arg = arg;
+    wg.alive = cfg.block;
+    wg.lanes.resize(cfg.block);
+    wg.waves.resize((cfg.block + 63) / 64);
+    if (cfg.block % 64) wg.waves.back().alive = cfg.block % 64;  // a partial last wavefront: the missing lanes are masked off
+    for (unsigned t = 0; t < cfg.block; ++t) {
+        lane_ctx &l = wg.lanes[t];
+        l.wg = &wg;
+        l.tid = t;
+        l.stack = stacks.get(t);
+        prepare_fiber(l);
+    }
+    while (wg.alive > 0) {
+        bool progressed = false;
+        for (lane_ctx &l : wg.lanes) {
+            if (l.done) continue;
+            if (l.wait_on) {
+                if (*l.wait_on == l.wait_val) continue;
+                l.wait_on = nullptr;
+            }
+            g_self = &l;
+            wavesim_switch(&wg.sched_sp, l.sp);
+            progressed = true;
+        }
+        if (!progressed) {
+            fprintf(stderr, "wavesim: block %u of %u (%u work-items): barrier %u/%u arrived;", wg.block_idx, wg.grid_dim, wg.block_dim,
+                    wg.barrier_arrived, wg.alive);
+            for (size_t i = 0; i < wg.waves.size(); ++i) {
+                fprintf(stderr, " wave %zu: %u/%u in wave op %u;", i, wg.waves[i].arrived, wg.waves[i].alive, wg.waves[i].tag);
+            }
+            fprintf(stderr, "\n");
+            for (lane_ctx &l : wg.lanes) {
+                if (!l.done && l.tid < 2) {
+                    Dl_info info{};
+                    dladdr(l.site, &info);
+                    fprintf(stderr, " [%u:%s @ +0x%zx]", l.tid, l.where, static_cast<size_t>(static_cast<char *>(l.site) - static_cast<char *>(info.dli_fbase)));
+                }
+            }
+            fprintf(stderr, "\n");
+            die("workgroup deadlock: work-items wait at a barrier or wave operation that the others never reach");
+        }
+    }
+    g_self = nullptr;
+}
+
+}  // namespace
+
+lane_ctx *self() { return g_self; }
+unsigned lane_thread_idx() { return g_self->tid; }
+unsigned lane_block_idx() { return g_self->wg->block_idx; }
+unsigned lane_block_dim() { return g_self->wg->block_dim; }
+unsigned lane_grid_dim() { return g_self->wg->grid_dim; }
+
+void barrier() {
+    lane_ctx *l = g_self;
+    wg_state *wg = l->wg;
+    const unsigned gen = wg->barrier_gen;
+    if (++wg->barrier_arrived == wg->alive) {
+        wg->barrier_arrived = 0;
+        ++wg->barrier_gen;
+        return;
+    }
+    l->wait_on = &wg->barrier_gen;
+    l->wait_val = gen;
+    l->where = "barrier";
+    l->site = __builtin_return_address(0);
+    yield_to_scheduler();
+}
+
+namespace {
+// deposit v, wait for the wavefront, return the buffer the values of this rendezvous sit in
+const uint64_t *rendezvous(uint64_t v, unsigned tag, void *site) {
+    lane_ctx *l = g_self;
+    wg_state *wg = l->wg;
+    wave_state &w = wg->waves[l->tid / 64];
+    const unsigned gen = w.gen;
+    uint64_t *buf = w.slot[gen & 1u];
+    if (w.arrived == 0) {
+        w.tag = tag;
+    } else if (w.tag != tag) {
+        die("lanes of one wavefront meet in different wave operations (divergent control flow around a shuffle / ballot / DPP)");
+    }
+    buf[l->tid & 63u] = v;
+    if (++w.arrived == w.alive) {
+        w.arrived = 0;
+        w.tag = op_none;
+        ++w.gen;
+    } else {
+        l->wait_on = &w.gen;
+        l->wait_val = gen;
+        l->where = tag == op_exchange ? "shuffle" : tag == op_ballot ? "ballot" : "dpp";
+        l->site = site;
+        yield_to_scheduler();
+    }
+    return buf;
+}
+}  // namespace
+
+uint64_t wave_exchange(uint64_t v, int src) {
+    const unsigned lane = g_self->tid & 63u;
+    const uint64_t *buf = rendezvous(v, op_exchange, __builtin_return_address(0));
+    return buf[(src >= 0 && src < 64) ? static_cast<unsigned>(src) : lane];
+}
+
+uint64_t wave_ballot(bool pred) {
+    const uint64_t *buf = rendezvous(pred ? 1u : 0u, op_ballot, __builtin_return_address(0));
+    const wave_state &w = g_self->wg->waves[g_self->tid / 64];
+    (void) w;
+    uint64_t mask = 0;
+    for (unsigned i = 0; i < 64; ++i) mask |= (buf[i] & 1u) << i;
+    return mask;
+}
+
+uint32_t update_dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask, unsigned bank_mask, bool bound_ctrl) {
+    const int lane = static_cast<int>(g_self->tid & 63u);
+    const uint64_t *buf = rendezvous(src, op_dpp, __builtin_return_address(0));
+    const int row = lane >> 4, in_row = lane & 15;
+    const bool enabled = ((row_mask >> row) & 1u) && ((bank_mask >> (in_row >> 2)) & 1u);
+    if (!enabled) return old;
+    int from = -1;  // source lane, -1 = out of range
+    if (ctrl <= 0xffu) {  // quad_perm
+        from = (lane & ~3) | static_cast<int>((ctrl >> (2 * (lane & 3))) & 3u);
+    } else if (ctrl >= 0x101u && ctrl <= 0x10fu) {  // row_shl:n -- lane i receives lane i + n of its row
+        const int s = in_row + static_cast<int>(ctrl - 0x100u);
+        if (s < 16) from = row * 16 + s;
+    } else if (ctrl >= 0x111u && ctrl <= 0x11fu) {  // row_shr:n -- lane i receives lane i - n of its row
+        const int s = in_row - static_cast<int>(ctrl - 0x110u);
+        if (s >= 0) from = row * 16 + s;
+    } else if (ctrl >= 0x121u && ctrl <= 0x12fu) {  // row_ror:n
+        from = row * 16 + ((in_row - static_cast<int>(ctrl - 0x120u)) & 15);
+    } else if (ctrl == 0x130u) {  // wave_shl:1
+        if (lane + 1 < 64) from = lane + 1;
+    } else if (ctrl == 0x134u) {  // wave_rol:1
+        from = (lane + 1) & 63;
+    } else if (ctrl == 0x138u) {  // wave_shr:1
+        if (lane - 1 >= 0) from = lane - 1;
+    } else if (ctrl == 0x13cu) {  // wave_ror:1
+        from = (lane - 1) & 63;
+    } else if (ctrl == 0x140u) {  // row_mirror
+        from = row * 16 + (15 - in_row);
+    } else if (ctrl == 0x141u) {  // row_half_mirror
+        from = row * 16 + ((in_row & 8) | (7 - (in_row & 7)));
+    } else if (ctrl == 0x142u) {  // row_bcast:15 -- lane 15 of each row to the whole next row
+        if (row > 0) from = (row - 1) * 16 + 15;
+    } else if (ctrl == 0x143u) {  // row_bcast:31 -- lane 31 to rows 2 and 3
+        if (row >= 2) from = 31;
+    } else {
+        die("unknown DPP control");
+    }
+    if (from < 0) return bound_ctrl ? 0u : old;
+    return static_cast<uint32_t>(buf[from]);
+}
+
+void sleep_hint() {
+    std::this_thread::yield();
+    yield_to_scheduler();
+}
+
+void run_grid(launch_cfg cfg, void (*fn)(void *), void *arg) {
+    if (cfg.grid == 0) return;
+    if (g_self) die("nested kernel launch");
+    unsigned resident = static_cast<unsigned>(wavesim_env_int("WAVESIM_MAX_RESIDENT", 32));
+    if (resident < 1) resident = 1;
+    if (resident > cfg.grid) resident = cfg.grid;
+    std::atomic<unsigned> next{0};
+    auto worker = [&] {
+        thread_stacks stacks;
+        for (;;) {
+            const unsigned b = next.fetch_add(1);
+            if (b >= cfg.grid) break;
+            run_workgroup(b, cfg, fn, arg, stacks);
+        }
+    };
+    if (resident == 1) {
+        worker();
+        return;
+    }
+    std::vector<std::thread> threads;
+    threads.reserve(resident);
+    for (unsigned i = 0; i < resident; ++i) threads.emplace_back(worker);
+    for (auto &t : threads) t.join();
+}
+
+}  // namespace wavesim
