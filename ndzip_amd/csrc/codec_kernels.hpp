@@ -529,114 +529,44 @@ NDZIP_DEV void forward_transform_hypercube(const typename profile<T, Dims>::word
     __syncthreads();  // all stencil reads done: `cube` may now be overwritten with the encoded run
 }
 
-// ---- phase 2 of encode, in three steps so a kernel can publish lengths before the planes are written ---------
-//
-// encoded_chunk: what one work-item contributes -- its chunk's head, plane words and plane count.
-//   f32: planes[0..31] = the 32 bit planes of its chunk (plane 0 = MSB plane).
-//   f64: lanes (2m, 2m+1) share chunk m.  The even lane holds values 0..31 of the chunk, which land in bits
-//        63..32 of every plane word (uint32 index 1 of the word), the odd lane values 32..63 (bits 31..0).
-//        planes[0..31] are this lane's half of planes 0..31 (built from the high halves of the values),
-//        planes[32..63] its half of planes 32..63 (low halves).
-template<int B>
-struct encoded_chunk {
-    uint32_t planes[B];
-    uint32_t head_hi;  // f64: bits 63..32 of the chunk head; f32: the head
-    uint32_t head_lo;  // f64: bits 31..0
-    uint32_t count;    // non-zero planes of the chunk (same on both lanes of an f64 pair)
-    uint32_t scan_in;  // what this work-item feeds into the chunk-offset scan (f64: only the even lane counts)
-};
+// ---- phase 2 of encode (f32; the f64 mapping lives in codec_kernels_wide.hpp) -----------------------------------------
+// A work-item holds one chunk: 32 residuals -> head (OR), count of non-zero planes, and -- after transpose32 -- the 32
+// plane words (plane 0 = MSB plane).  The kernel publishes the lengths first and writes the planes later:
 
-// 2a: head + in-register bit transpose (no LDS, no barrier)
-template<typename T, int Dims>
-NDZIP_DEV void encode_chunk(typename profile<T, Dims>::word (&r)[vals_per_thread], int t, encoded_chunk<profile<T, Dims>::B> &c) {
-    constexpr int B = profile<T, Dims>::B;
-    if constexpr (B == 32) {
-        uint32_t head = 0;
+// head word and plane count of the chunk held in r[32]
+NDZIP_DEV uint32_t chunk_head32(const uint32_t (&r)[vals_per_thread]) {
+    uint32_t head = 0;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) head |= r[j];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) c.planes[j] = r[j];
-        transpose32(c.planes);
-        c.head_hi = head;
-        c.head_lo = 0;
-        c.count = static_cast<uint32_t>(__builtin_popcount(head));
-        c.scan_in = c.count;
-    } else {
-        uint64_t own_or = 0;
-        uint32_t(&hi)[32] = *reinterpret_cast<uint32_t(*)[32]>(&c.planes[0]);
-        uint32_t(&lo)[32] = *reinterpret_cast<uint32_t(*)[32]>(&c.planes[32]);
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            own_or |= r[j];
-            hi[j] = static_cast<uint32_t>(r[j] >> 32);
-            lo[j] = static_cast<uint32_t>(r[j]);
-        }
-        const uint64_t head = own_or | __shfl_xor(own_or, 1, 64);
-        transpose32(hi);
-        transpose32(lo);
-        c.head_hi = static_cast<uint32_t>(head >> 32);
-        c.head_lo = static_cast<uint32_t>(head);
-        c.count = static_cast<uint32_t>(__builtin_popcountll(head));
-        c.scan_in = (t & 1) == 0 ? c.count : 0u;
-    }
+    for (int j = 0; j < 32; ++j) head |= r[j];
+    return head;
 }
 
-// 2c: write head and non-zero planes.  `run` = first uint32 of this hypercube's encoded run in LDS, `chunk_excl` =
-// number of plane words of all earlier chunks of the hypercube.
-template<typename T, int Dims>
-NDZIP_DEV void write_chunk(const encoded_chunk<profile<T, Dims>::B> &c, uint32_t *run, uint32_t chunk_excl, int t) {
-    using P = profile<T, Dims>;
-    constexpr int B = P::B;
-    uint32_t pos = P::head_words + chunk_excl;
-    if constexpr (B == 32) {
-        run[t] = c.head_hi;
+// Compaction of one chunk into the encoded run of its hypercube in LDS: head word at run[t], the non-zero planes from
+// run[head_words + chunk_excl] on (`chunk_excl` = plane words of all earlier chunks of the hypercube).  `run_word0` = uint32
+// index of run[0] inside a 16-byte aligned LDS region, for the alignment test of the dense path:
+// a chunk that keeps all 32 planes at a 16-byte aligned position goes out as eight 16-byte writes -- when whole wavefronts
+// are that dense (incompressible data) the word-by-word compaction writes at a lane stride of 32 words, a 32-way bank
+// conflict on each of its 32 instructions (random bits: compress 0.345 -> 0.29 ms for 512^3).
+NDZIP_DEV void write_planes32(uint32_t *run, uint32_t run_word0, int t, uint32_t head, uint32_t chunk_excl, const uint32_t (&planes)[32]) {
+    constexpr uint32_t head_words = hc_size / 32;
+    uint32_t pos = head_words + chunk_excl;
+    run[t] = head;
+    const bool dense = head == 0xffffffffu && ((run_word0 + pos) & 3u) == 0;
+    if (dense) {
+        char *dst = reinterpret_cast<char *>(run + pos);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (c.planes[i] != 0) run[pos++] = c.planes[i];
+        for (int i = 0; i < 8; ++i) {
+            vec16 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v.w[j] = planes[4 * i + j];
+            lds_write16(dst + 16 * i, v);
         }
     } else {
-        const uint32_t half = (t & 1) == 0 ? 1u : 0u;  // even lane supplies bits 63..32 = uint32 index 1
-        run[2 * (t >> 1) + half] = half ? c.head_hi : c.head_lo;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            if ((c.head_hi >> (31 - i)) & 1u) {
-                run[2 * pos + half] = c.planes[i];
-                ++pos;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if ((c.head_lo >> (31 - i)) & 1u) {
-                run[2 * pos + half] = c.planes[32 + i];
-                ++pos;
-            }
+            if (planes[i] != 0) run[pos++] = planes[i];
         }
     }
-}
-
-// residuals r[32] of work-item t -> encoded run at cube[0 .. L), returns L (one hypercube, 128 work-items)
-template<typename T, int Dims>
-NDZIP_DEV uint32_t encode_residuals(typename profile<T, Dims>::word (&r)[vals_per_thread], char *cube, uint32_t *xchg, int t) {
-    using P = profile<T, Dims>;
-    const int lane = t & 63, wave = t >> 6;
-    encoded_chunk<P::B> c;
-    encode_chunk<T, Dims>(r, t, c);
-    const uint32_t incl = wave_inclusive_scan(c.scan_in, lane);  // 2b: chunk offsets
-    if (lane == 63) xchg[wave] = incl;
-    __syncthreads();
-    const uint32_t total = P::head_words + xchg[0] + xchg[1];
-    // (for an f64 pair the inclusive value at the odd lane already contains the pair's count)
-    write_chunk<T, Dims>(c, reinterpret_cast<uint32_t *>(cube), (wave ? xchg[0] : 0u) + incl - c.count, t);
-    __syncthreads();
-    return total;
-}
-
-template<typename T, int Dims, bool Aligned>
-NDZIP_DEV uint32_t encode_hypercube(const typename profile<T, Dims>::word *__restrict__ in, const grid_geom &gg,
-        uint64_t origin, bool active, char *cube, const char *zero, uint32_t *xchg, int t) {
-    typename profile<T, Dims>::word r[vals_per_thread];
-    forward_transform_hypercube<T, Dims, Aligned>(in, gg, origin, active, cube, zero, t, r);
-    return encode_residuals<T, Dims>(r, cube, xchg, t);
 }
 
 // ---------------------------------------------------------------------------------------------------------

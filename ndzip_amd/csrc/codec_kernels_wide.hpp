@@ -1,29 +1,26 @@
-// ndzip_amd/csrc/codec_kernels_wide.hpp -- ENCODE with 256 work-items per hypercube ("wide" mapping): a work-item owns 16
-// consecutive cube-local values, a chunk of B values spans B/16 lanes (2 for f32, 4 for f64).
+// ndzip_amd/csrc/codec_kernels_wide.hpp -- f64 ENCODE with 256 work-items per hypercube ("wide" mapping): a work-item owns
+// 16 consecutive cube-local values, a chunk of 64 values spans a lane quad.
 //
 // Why: with the 128-work-item mapping of codec_kernels.hpp an f64 work-item carries 64 VGPRs of residuals and 64 VGPRs of
-// plane words -- too much to keep an encoded tile in registers across an iteration, so the f64 compress kernel had to write
-// a tile out in the iteration that encoded it, with its look-back on the critical path.  Here a work-item carries, per 16
-// values, sizeof(W)*4 VGPRs of values, the same of prefetch and -- after the transpose -- the same of plane words.  For
-// f64 that is exactly the register picture of the 128-lane f32 kernel, so its register-buffered deferred-write-out
-// pipeline carries over (2D f64 8192^2: 0.253 -> 0.210 ms; 3D f64 512^3: 0.479 -> 0.391 ms).  For f32 it halves the
-// registers and the tile (one hypercube, 16 KiB), i.e. twice the workgroups per CU and half the pipeline fill / drain.
+// plane words -- too much to keep an encoded tile in registers across an iteration, so an f64 compress kernel of that shape
+// has to write a tile out in the iteration that encoded it, with its look-back on the critical path.  Here a work-item
+// carries, per 16 values, 32 VGPRs of values, the same of prefetch and -- after the transpose -- the same of plane words:
+// exactly the register picture of the 128-lane f32 kernel, so its register-buffered deferred-write-out pipeline carries over
+// (2D f64 8192^2: 0.253 -> 0.210 ms; 3D f64 512^3: 0.479 -> 0.391 ms).  (The same mapping for f32 -- one 16 KiB hypercube
+// per tile -- doubles the tiles, i.e. tickets, descriptors and look-backs, and measured 0.284 vs 0.208 ms on 512^3; it is
+// not kept.)
 //
-// Bit transpose of a chunk over its lanes:
-//   f64 (lane quad q = 0..3, values 16q .. 16q+15): the two lanes of a pair swap halves -- the even lane ends up with the
-//       HIGH dwords of the pair's 32 values, the odd lane with the LOW dwords (16 DPP moves) -- then one 32x32 transpose per
-//       lane.  Lane 0 holds, for planes 0..31 (bits 63..32), the dword covering values 0..31 = the HIGH dword of the 64-bit
-//       plane word; lane 2 the LOW dword of the same planes (values 32..63); lanes 1 / 3 likewise for planes 32..63.
-//   f32 (lane pair, values 16p .. 16p+15): the first stage of the 32x32 block-swap network (rows r <-> r+16) IS the
-//       exchange between the two lanes (16 DPP moves + 16 v_perm); the remaining four stages stay inside a lane.  The even
-//       lane ends up with planes 0..15, the odd lane with planes 16..31.
-// Each lane compacts its own plane words (32 resp. 16 conditional LDS writes).
+// Bit transpose of a chunk over its lane quad q = 0..3 (values 16q .. 16q+15): the two lanes of a pair swap halves -- the
+// even lane ends up with the HIGH dwords of the pair's 32 values, the odd lane with the LOW dwords (16 DPP moves) -- then one
+// 32x32 transpose per lane.  Lane 0 holds, for planes 0..31 (bits 63..32), the dword covering values 0..31 = the HIGH dword
+// of the 64-bit plane word; lane 2 the LOW dword of the same planes (values 32..63); lanes 1 / 3 likewise for planes 32..63.
+// Each lane compacts its own 32 plane words (conditional LDS writes).
 //
 // Reference behaviour restated here (not its structure): load_hypercube + rotate_left_1 (src/ndzip/cuda_codec.inl:30-56,
 // common.hh:436-440), block_transform (cuda_codec.inl:68-126; the per-axis passes are fused into one stencil),
 // complement_negative (common.hh:442-449), write_transposed_chunks = chunk head, BxB bit transpose, zero-word compaction
-// (cuda_codec.inl:185-275; stream layout common.hh:328-366).  Parity: every compress test of tests/test_hip_*.py runs through
-// this mapping for float64; tests/test_wide_mapping_model.py is its executable description on the CPU.
+// (cuda_codec.inl:185-275; stream layout common.hh:328-366).  Parity: every float64 compress test (tests/test_hip_*.py on the
+// GPU, the functional-model tests on the CPU) runs through this mapping; stage tests call these functions one at a time.
 #pragma once
 
 #include "codec_kernels.hpp"
@@ -233,64 +230,6 @@ struct coding<uint64_t> {
                 run32[w] = planes[i];
                 w += 2;
             }
-        }
-    }
-};
-
-template<>
-struct coding<uint32_t> {
-    static constexpr int lanes_per_chunk = 2;
-    static constexpr int planes_per_lane = 16;
-    static constexpr uint32_t head_words = hc_size / 32;
-    static constexpr uint32_t w32 = 1;
-    struct held {
-        uint32_t head_bits;  // head bits of this lane's 16 planes in bits 31..16
-        uint32_t head_word;  // the chunk head (stored by the even lane)
-        uint32_t slot;
-    };
-    NDZIP_DEV static uint32_t head_and_count(const uint32_t (&r)[vals], uint32_t &head, uint32_t &unused) {
-        uint32_t own = 0;
-#pragma unroll
-        for (int j = 0; j < vals; ++j) own |= r[j];
-        head = own | pair_swap(own);
-        unused = 0;
-        return static_cast<uint32_t>(__builtin_popcount(head));
-    }
-    NDZIP_DEV static void transpose(const uint32_t (&r)[vals], int t, uint32_t (&planes)[planes_per_lane]) {
-        const bool odd = (t & 1) != 0;
-        // stage 16 of the block-swap network across the lane pair: row j lives in the even lane, row j + 16 in the odd lane
-#pragma unroll
-        for (int j = 0; j < vals; ++j) {
-            const uint32_t got = pair_swap(r[j]);
-            const uint32_t a = odd ? got : r[j], b = odd ? r[j] : got;  // a = row j, b = row j + 16
-            planes[j] = odd ? __builtin_amdgcn_perm(a, b, 0x05040100u)   // row j + 16: (a << 16) | (b & 0x0000ffff)
-                            : __builtin_amdgcn_perm(a, b, 0x07060302u);  // row j:      (a & 0xffff0000) | (b >> 16)
-        }
-        // stages 8, 4, 2, 1 inside the lane (16 rows)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t a = planes[j], b = planes[j + 8];
-            planes[j] = __builtin_amdgcn_perm(a, b, 0x07030501u);      // (a & 0xff00ff00) | ((b >> 8) & 0x00ff00ff)
-            planes[j + 8] = __builtin_amdgcn_perm(a, b, 0x06020400u);  // ((a << 8) & 0xff00ff00) | (b & 0x00ff00ff)
-        }
-        swap_stage<4, 0x0f0f0f0fu, 16>(planes);
-        swap_stage<2, 0x33333333u, 16>(planes);
-        swap_stage<1, 0x55555555u, 16>(planes);
-    }
-    NDZIP_DEV static held hold(int t, uint32_t head, uint32_t, uint32_t chunk_pos) {
-        const bool odd = (t & 1) != 0;
-        held h;
-        h.head_bits = odd ? head << 16 : head;  // even lane: planes 0..15 = head bits 31..16; odd lane: planes 16..31 = bits 15..0
-        h.head_word = head;
-        h.slot = chunk_pos + (odd ? static_cast<uint32_t>(__builtin_popcount(head >> 16)) : 0u);
-        return h;
-    }
-    NDZIP_DEV static void write(const held &h, const uint32_t (&planes)[planes_per_lane], uint32_t *run32, int t) {
-        if ((t & 1) == 0) run32[static_cast<uint32_t>(t) >> 1] = h.head_word;
-        uint32_t w = h.slot;
-#pragma unroll
-        for (int i = 0; i < planes_per_lane; ++i) {
-            if ((h.head_bits >> (31 - i)) & 1u) run32[w++] = planes[i];
         }
     }
 };

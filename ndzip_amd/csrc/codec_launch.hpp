@@ -12,12 +12,11 @@ namespace ndzip_hip {
 // agent-scope 8-byte store, so the value is its own flag (no fences; MI355X guide section 6 G16 "R2").
 using tile_desc = unsigned long long;
 
-// Scratch behind the descriptors: 16 experiment counters, then one ticket counter per class, each in its own 128-byte
-// line (see max_ticket_classes in codec_launch.inl).  Sizes in tile_desc units.
-constexpr unsigned max_ticket_classes = 64;      // counters reserved in the scratch
-constexpr unsigned default_ticket_classes = 16;  // classes a launch uses
+// Scratch in front of the descriptors: 16 experiment counters, then one ticket counter per class, each in its own 128-byte
+// line, then the 'workgroups done' line (see release_tickets in codec_launch.inl).  Sizes in tile_desc units.
+constexpr unsigned ticket_classes = 16;       // ticket counters a launch uses (1 when the grid is smaller than that)
 constexpr unsigned ticket_stride_words = 32;  // uint32 words between the counters of consecutive classes
-constexpr unsigned scratch_extra_descs = 16 + (max_ticket_classes + 1) * ticket_stride_words / 2;  // + the 'workgroups done' line
+constexpr unsigned scratch_extra_descs = 16 + (ticket_classes + 1) * ticket_stride_words / 2;
 
 struct compress_args {
     const void *in;        // device, value_type[num_elements]

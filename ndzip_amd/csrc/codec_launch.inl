@@ -30,21 +30,10 @@ using T_ = NDZIP_T;
 // lines of the 64-byte cube rows); f64 rows already are >= 128 bytes and the cube is twice as large in LDS.
 template<typename T, int Dims>
 struct tile_cfg {
-#ifdef NDZIP_EXP_K
-    static constexpr int K = sizeof(T) == 4 ? NDZIP_EXP_K : 1;
-#else
     static constexpr int K = sizeof(T) == 4 ? 2 : 1;
-#endif
     static constexpr int threads = K * threads_per_hc;
     using W = typename word_of<T>::type;
     using L = lds_layout<W>;
-    // resident workgroups per CU the LDS admits (160 KiB) -> wavefronts per SIMD the register budget must allow
-    static constexpr int min_waves_per_simd = sizeof(T) == 4 ? 3 : 2;
-#ifdef NDZIP_EXP_LOOKBACK_FIRST
-    static constexpr bool lookback_before_prefetch = true;
-#else
-    static constexpr bool lookback_before_prefetch = false;
-#endif
     static constexpr uint32_t xchg_bytes = 32;  // per hypercube: 2 x uint32 + 2 x W
     // bytes between the staging regions of a tile's hypercubes: = 128 mod 256, see stage_pair_regs
     static constexpr uint32_t cube_stride = L::cube_bytes + (K > 1 ? 128 : 0);
@@ -82,16 +71,10 @@ NDZIP_DEV void desc_store(tile_desc *p, tile_desc v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Ticket n of class c -> tile.  Plain interleave (tile = n * classes + c) for up to 16 classes.  With 64 classes
-// (experiments, NDZIP_HIP_CLASSES=64) the class is (XCD x = c % 8, j = c / 8) -- a block b runs on XCD b % 8 and has class
-// b % 64 -- and the tile is (n * 8 + x) * 8 + j: eight CONSECUTIVE tiles go to eight workgroups of one XCD at the same ticket
-// number, so neighbouring tiles meet in one L2.  Either way a class's tiles increase with its tickets.
-NDZIP_DEV uint32_t tile_of_ticket(uint32_t ticket, uint32_t cls, uint32_t num_classes) {
-    if (num_classes == 64) return ((ticket * 8u + (cls & 7u)) * 8u) + (cls >> 3);
-    return ticket * num_classes + cls;
-}
+// Ticket n of class c -> tile: plain interleave.  A class's tiles increase with its tickets.
+NDZIP_DEV uint32_t tile_of_ticket(uint32_t ticket, uint32_t cls, uint32_t num_classes) { return ticket * num_classes + cls; }
 
-// tickets[class * ticket_stride_words] = next ticket of the class; tickets[max_ticket_classes * ticket_stride_words] =
+// tickets[class * ticket_stride_words] = next ticket of the class; tickets[ticket_classes * ticket_stride_words] =
 // number of workgroups that have drawn their last ticket
 // The last workgroup to leave also looks at the error word: a launch that hit a look-back timeout has published offsets
 // that are too small, so its stream is garbage although every write stayed in bounds -- the stream length is then
@@ -100,7 +83,7 @@ NDZIP_DEV uint32_t tile_of_ticket(uint32_t ticket, uint32_t cls, uint32_t num_cl
 // each workgroup's own out_len / err stores before its 'done' increment.
 NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid, uint32_t *err, uint32_t *out_len) {
     if (tid != 0) return;
-    uint32_t *done = tickets + max_ticket_classes * ticket_stride_words;
+    uint32_t *done = tickets + ticket_classes * ticket_stride_words;
     __threadfence();
     if (atomicAdd(done, 1u) == gridDim.x - 1) {
         for (uint32_t c = 0; c < num_classes; ++c) tickets[c * ticket_stride_words] = 0;
@@ -335,162 +318,6 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
 // microsecond.  With 16 counters packed into one line the ticket rate capped the whole kernel (tools/membench2.hip:
 // the bare load loop 0.211 ms vs 0.101 ms with the counters 64+ bytes apart; static assignment 0.114 ms).
 
-template<typename T, int Dims, bool Aligned>
-__global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (tile_cfg<T, Dims>::min_waves_per_simd))
-compress_kernel(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
-        typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
-        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags_arg, const uint32_t epoch) {
-    const desc_ref desc{desc_base, epoch};
-    NDZIP_EXP_FLAGS(exp_flags_arg)
-    using C = tile_cfg<T, Dims>;
-    using W = typename C::W;
-    using L = typename C::L;
-    using P = profile<T, Dims>;
-    constexpr int K = C::K;
-    constexpr int NW = C::threads / 64;            // wavefronts per workgroup (2 per hypercube)
-    constexpr uint32_t w32 = sizeof(W) / 4;        // uint32 per stream word
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = static_cast<int>(threadIdx.x);
-    const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
-    const int lane = tid & 63, wave = tid >> 6;
-    char *cube = smem + grp * C::cube_stride;       // staging of this group's hypercube
-    char *zero_region = smem + K * C::cube_stride;
-    char *zero = zero_region + L::template zero_offset<Dims>();
-    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
-    uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);              // the K encoded runs, back to back
-
-    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
-
-    const uint32_t ntiles = (gg.nhc + K - 1) / K;
-    const uint32_t cls = blockIdx.x % num_classes;
-    uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
-    if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);  // (own slot: see compress_kernel_db)
-    __syncthreads();  // (also orders the zero block before the first stencil read)
-    uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
-
-#ifdef NDZIP_EXP_PHASE_TIMING
-    const bool timing = (exp_flags & 16u) != 0;
-    uint32_t ticks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t t_prev = timing ? __builtin_readcyclecounter() : 0;
-#define NDZIP_PHASE(i)                                          \
-    if (timing) {                                               \
-        const uint64_t now_ = __builtin_readcyclecounter();     \
-        ticks[i] += static_cast<uint32_t>(now_ - t_prev);       \
-        t_prev = now_;                                          \
-    }
-#else
-#define NDZIP_PHASE(i)
-#endif
-
-    // Input of the tile about to be processed, prefetched into registers.  The loads are unconditional (a
-    // conditional load would keep the previous registers live across the whole loop): out-of-range hypercubes
-    // re-read the last one and the result is ignored.
-    input_regs<W, Aligned> pre;
-    {
-        uint32_t first_hc = tile * K + grp;
-        if (first_hc >= gg.nhc) first_hc = gg.nhc - 1;
-        load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, first_hc), t, pre);
-    }
-    while (tile < ntiles) {
-        const uint32_t hc = tile * K + grp;
-        const bool active = hc < gg.nhc;
-        if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
-        NDZIP_PHASE(0)  // wait for the prefetched loads + stage
-        __syncthreads();
-        W r[vals_per_thread];
-        stencil_residuals<T, Dims>(cube, zero, t, r);
-        NDZIP_PHASE(1)  // barrier + stencil
-        __syncthreads();  // all stencil reads done: the staging region may now receive the encoded runs
-
-        encoded_chunk<P::B> c;
-        encode_chunk<T, Dims>(r, t, c);
-        const uint32_t incl = wave_inclusive_scan(active ? c.scan_in : 0u, lane);
-        if (lane == 63) misc[wave] = incl;
-        NDZIP_PHASE(2)  // barrier + transpose + chunk scan
-        __syncthreads();
-        // lengths of the K hypercubes of this tile, known to every work-item
-        uint32_t run_start = 0, aggregate = 0, my_len = 0;
-#pragma unroll
-        for (int g = 0; g < K; ++g) {
-            const uint32_t len_g = tile * K + g < gg.nhc ? P::head_words + misc[2 * g] + misc[2 * g + 1] : 0u;
-            if (g < grp) run_start += len_g;
-            if (g == grp) my_len = len_g;
-            aggregate += len_g;
-        }
-        // (measured, 2D f64 8192^2: ticket drawn at the top of the iteration and consumed before this store 0.254 vs
-        // 0.245 ms; aggregate + ticket from wavefront 1 and the look-back wavefront prefetching after its look-back 0.27;
-        // 128 descriptors per hop as 16-byte loads 0.266; fewer ticket classes slower)
-        uint32_t next_ticket = 0;
-        if (tid == 0) {
-            publish_aggregate(desc, tile, aggregate);      // as early as possible: successors wait on this
-            next_ticket = atomicAdd(ticket_counter, 1u);   // latency hidden behind the plane writes
-        }
-        if (active && !(exp_flags & 4u)) {
-            write_chunk<T, Dims>(c, tile_run + run_start * w32, ((wave & 1) ? misc[2 * grp] : 0u) + incl - c.count, t);
-        }
-        if (tid == 0) misc[NW + 1] = next_ticket;
-        NDZIP_PHASE(3)  // barrier + publish + plane writes
-        __syncthreads();  // next ticket known to all; encoded runs complete in LDS
-        const uint32_t next_tile = tile_of_ticket(misc[NW + 1], cls, num_classes);
-        uint32_t next_hc = next_tile * K + grp;
-        if (next_hc >= gg.nhc) next_hc = gg.nhc - 1;
-        // Vector loads return in order, so descriptor reads queued behind this wavefront's own prefetch pay its full
-        // latency on the first hop.  Measured trade-off (profiles/): issuing the whole prefetch first
-        // still wins for the single-buffered kernel because the tile's loads then overlap the look-back wait.
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!C::lookback_before_prefetch) {
-            load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (wave == 0) {
-            // (exp_flags: timing experiments only, see tools/ablate.sh; 0 in production)
-#ifdef NDZIP_EXP_PHASE_TIMING
-            const uint32_t exclusive = (exp_flags & 1u) ? tile * static_cast<uint32_t>(K * P::max_hc_words)
-                                                        : resolve_exclusive_prefix_impl<false>(desc, tile, aggregate, err, lane, lookback_windows{}, &ticks[10], &ticks[11]);
-#else
-            const uint32_t exclusive = (exp_flags & 1u) ? tile * static_cast<uint32_t>(K * P::max_hc_words)
-                                                        : resolve_exclusive_prefix(desc, tile, aggregate, err, lane);
-#endif
-            if (tid == 0) misc[NW] = exclusive;
-        }
-        NDZIP_PHASE(4)  // look-back (wave 0)
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (C::lookback_before_prefetch) {
-            load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, next_hc), t, pre);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        NDZIP_PHASE(5)  // prefetch issue
-        __syncthreads();  // tile prefix known
-        const uint32_t prefix = misc[NW];
-        if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, aggregate, tid);
-        if (active && t == 0) {
-            header[hc] = prefix + run_start + my_len;  // offset_after(hc), common.hh:342-347
-            if (hc == gg.nhc - 1) {
-                if (out_len) *out_len = len_extra + prefix + run_start + my_len;
-                // zero the header pad of 64-bit streams with an odd hypercube count (cuda_codec.inl:446-452)
-                if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
-            }
-        }
-        NDZIP_PHASE(6)  // barrier + copy-out + header
-        __syncthreads();  // copy-out has read the runs before the next tile is staged over them
-        NDZIP_PHASE(7)  // final barrier
-        tile = next_tile;
-    }
-    // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
-    // visible); the descriptors need no clearing (epoch).
-    release_tickets(tickets, num_classes, tid, err, out_len);
-#undef NDZIP_PHASE
-#ifdef NDZIP_EXP_PHASE_TIMING
-    if (timing && tid == 0) {
-        unsigned long long *acc = reinterpret_cast<unsigned long long *>(tickets) - 16;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
-        atomicAdd(acc + 15, 1ull);
-    }
-#endif
-}
-
 // ---- deferred write-out variant (f32) --------------------------------------------------------------------------------
 // A tile is written out ONE ITERATION after it was encoded:
 //   * its look-back window is read asynchronously at the top of the next iteration (before that wavefront's prefetch
@@ -626,8 +453,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (have_cur) {
             NDZIP_PHASE(1)  // B1 + window issue
             stencil_residuals<T, Dims>(cube, zero, t, r);
-#pragma unroll
-            for (int j = 0; j < 32; ++j) head |= r[j];
+            head = chunk_head32(r);
             count = active ? static_cast<uint32_t>(__builtin_popcount(head)) : 0u;
             incl = wave_inclusive_scan(count, lane);
             if (lane == 63) misc[wave] = incl;
@@ -662,29 +488,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (have_prev) {
             // the previous tile's planes leave the registers: compact them into the (now free) staging region
             if (prev_active && !(exp_flags & 4u)) {
-                uint32_t *run = tile_run + prev_run_start;
-                uint32_t pos = P::head_words + prev_chunk_excl;
-                run[t] = prev_head;
-                // A chunk that keeps all 32 planes at a 16-byte aligned position goes out as eight 16-byte writes: when
-                // whole wavefronts are that dense (incompressible data) the word-by-word compaction below writes at a
-                // lane stride of 32 words, a 32-way bank conflict on each of its 32 instructions (random bits: compress
-                // 0.345 -> 0.29 ms for 512^3).
-                const bool dense = prev_head == 0xffffffffu && ((prev_run_start + pos) & 3u) == 0;
-                if (dense) {
-                    char *dst = reinterpret_cast<char *>(run + pos);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        vec16 v;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v.w[j] = planes[4 * i + j];
-                        lds_write16(dst + 16 * i, v);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) {
-                        if (planes[i] != 0) run[pos++] = planes[i];
-                    }
-                }
+                write_planes32(tile_run + prev_run_start, prev_run_start, t, prev_head, prev_chunk_excl, planes);
             }
         }
         NDZIP_PHASE(3)  // plane writes (prev)
@@ -759,11 +563,7 @@ struct wide_cfg {
     static constexpr int threads = wide::threads;
     static constexpr int NW = threads / 64;
     static constexpr uint32_t smem_bytes = wide::layout<W>::cube_bytes + wide::layout<W>::zero_bytes + 64;
-#ifdef NDZIP_EXP_WIDE_WAVES
-    static constexpr int min_waves_per_simd = sizeof(W) == 8 ? 3 : NDZIP_EXP_WIDE_WAVES;
-#else
-    static constexpr int min_waves_per_simd = sizeof(W) == 8 ? 3 : 5;
-#endif
+    static constexpr int min_waves_per_simd = 3;
     static constexpr int early_vectors = wide::input_regs<W>::NV / 2;
 };
 
@@ -962,20 +762,26 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
             cube + mis * sizeof(W), xchg, t);
 }
 
-// ---- stage kernels for the parity tests: exactly one hypercube, 128 work-items ---------------------------------
+// ---- stage kernels for the parity tests: exactly one hypercube, through the SAME device functions the production kernels
+// call (mirror of the reference's stage tests, src/test/codec_profile_test.inl:514-549, :552-729, :735-801, :889-947) --------
 
+// 128 work-items: the f32 encode stages (stage_hypercube_regs / stencil_residuals / chunk_head32 / transpose32 /
+// write_planes32 = what compress_kernel_db runs) and the decode stages of both types (decode_residuals /
+// inverse_transform_hypercube = what decompress_kernel runs)
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__(threads_per_hc)
 debug_stage_kernel(int stage, const grid_geom gg, uint32_t hc, const typename word_of<T>::type *__restrict__ in,
         typename word_of<T>::type *__restrict__ out, uint32_t *out_len) {
     using W = typename word_of<T>::type;
     using L = lds_layout<W>;
+    using P = profile<T, Dims>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *cube = smem;
     char *zero_region = smem + L::cube_bytes;
     char *zero = zero_region + L::template zero_offset<Dims>();
     uint32_t *xchg = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);
     const int t = static_cast<int>(threadIdx.x);
+    const int lane = t & 63, wave = t >> 6;
     for (uint32_t i = t; i < L::zero_bytes / 4; i += threads_per_hc) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
 
     W r[vals_per_thread];
@@ -983,15 +789,27 @@ debug_stage_kernel(int stage, const grid_geom gg, uint32_t hc, const typename wo
         forward_transform_hypercube<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, hc), true, cube, zero, t, r);
         for (int j = 0; j < vals_per_thread; ++j) out[t * 32 + j] = r[j];
     } else if (stage == debug_encode_residuals) {
-        for (int j = 0; j < vals_per_thread; ++j) r[j] = in[t * 32 + j];
-        __syncthreads();
-        const uint32_t len = encode_residuals<T, Dims>(r, cube, xchg, t);
-        const W *src = reinterpret_cast<const W *>(cube);
-        for (uint32_t w = t; w < len; w += threads_per_hc) out[w] = src[w];
-        if (t == 0) *out_len = len;
+        if constexpr (sizeof(W) == 4) {
+            for (int j = 0; j < vals_per_thread; ++j) r[j] = in[t * 32 + j];
+            const uint32_t head = chunk_head32(r);
+            const uint32_t count = static_cast<uint32_t>(__builtin_popcount(head));
+            const uint32_t incl = wave_inclusive_scan(count, lane);
+            if (lane == 63) xchg[wave] = incl;
+            __syncthreads();
+            uint32_t planes[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) planes[j] = r[j];
+            transpose32(planes);
+            write_planes32(reinterpret_cast<uint32_t *>(cube), 0, t, head, (wave ? xchg[0] : 0u) + incl - count, planes);
+            __syncthreads();
+            const uint32_t len = P::head_words + xchg[0] + xchg[1];
+            const W *src = reinterpret_cast<const W *>(cube);
+            for (uint32_t w = t; w < len; w += threads_per_hc) out[w] = src[w];
+            if (t == 0) *out_len = len;
+        }
     } else if (stage == debug_decode_residuals) {
         W *dst = reinterpret_cast<W *>(cube);
-        for (uint32_t w = t; w < profile<T, Dims>::max_hc_words; w += threads_per_hc) dst[w] = in[w];
+        for (uint32_t w = t; w < P::max_hc_words; w += threads_per_hc) dst[w] = in[w];
         __syncthreads();
         decode_residuals<T, Dims>(cube, xchg, t, r);
         for (int j = 0; j < vals_per_thread; ++j) out[t * 32 + j] = r[j];
@@ -999,6 +817,55 @@ debug_stage_kernel(int stage, const grid_geom gg, uint32_t hc, const typename wo
         for (int j = 0; j < vals_per_thread; ++j) r[j] = in[t * 32 + j];
         __syncthreads();
         inverse_transform_hypercube<T, Dims, Aligned>(r, out, gg, hc_origin<Dims>(gg, hc), true, cube, xchg, t);
+    }
+}
+
+// 256 work-items: the f64 encode stages (wide::load_regs / stage_regs / stencil / coding = what compress_kernel_wide runs)
+template<int Dims, bool Aligned>
+__global__ void __launch_bounds__(wide::threads)
+debug_stage_wide_kernel(int stage, const grid_geom gg, uint32_t hc, const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+        uint32_t *out_len) {
+    using W = uint64_t;
+    using L = wide::layout<W>;
+    using E = wide::coding<W>;
+    constexpr int NW = wide::threads / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *cube = smem;
+    char *zero_region = smem + L::cube_bytes;
+    char *zero = zero_region + L::zero_offset;
+    uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);
+    const int t = static_cast<int>(threadIdx.x);
+    const int lane = t & 63, wave = t >> 6;
+    for (uint32_t i = t; i < L::zero_bytes / 4; i += wide::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
+
+    W r[wide::vals];
+    if (stage == debug_forward_transform) {
+        wide::input_regs<W> pre;
+        wide::load_regs<W, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, hc), t, pre);
+        wide::stage_regs<W>(pre, cube, t);
+        __syncthreads();
+        wide::stencil<W, Dims>(cube, zero, t, r);
+        for (int j = 0; j < wide::vals; ++j) out[t * wide::vals + j] = r[j];
+    } else if (stage == debug_encode_residuals) {
+        for (int j = 0; j < wide::vals; ++j) r[j] = in[t * wide::vals + j];
+        uint32_t head_a = 0, head_b = 0;
+        const uint32_t count = E::head_and_count(r, head_a, head_b);
+        const uint32_t incl = wave_inclusive_scan((t & (E::lanes_per_chunk - 1)) == 0 ? count : 0u, lane);
+        if (lane == 63) misc[wave] = incl;
+        __syncthreads();
+        uint32_t total = E::head_words, chunk_excl = 0;
+        for (int w = 0; w < NW; ++w) {
+            total += misc[w];
+            if (w < wave) chunk_excl += misc[w];
+        }
+        chunk_excl += incl - count;
+        uint32_t planes[E::planes_per_lane];
+        E::transpose(r, t, planes);
+        E::write(E::hold(t, head_a, head_b, E::head_words + chunk_excl), planes, reinterpret_cast<uint32_t *>(cube), t);
+        __syncthreads();
+        const W *src = reinterpret_cast<const W *>(cube);
+        for (uint32_t w = t; w < total; w += wide::threads) out[w] = src[w];
+        if (t == 0) *out_len = total;
     }
 }
 
@@ -1017,108 +884,66 @@ __global__ void debug_transpose_kernel(const uint32_t *in, uint32_t *out, uint32
     for (int j = 0; j < 32; ++j) out[i * 32 + j] = x[j];
 }
 
-template<typename W, int Dims, bool Aligned>
-hipError_t launch_compress_wide(const compress_args &a) {
-    using C = wide_cfg<W>;
-    const uint32_t ntiles = a.gg.nhc;
-    if (ntiles == 0) return hipSuccess;
-    auto kernel = compress_kernel_wide<W, Dims, Aligned>;
-    static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
-        int api = 0;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                static_cast<int>(C::smem_bytes));
-        if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel, C::threads, C::smem_bytes);
-        if (e != hipSuccess) return e;
-        const int by_lds = static_cast<int>((160u * 1024u) / C::smem_bytes);
-        blocks_per_cu = api < by_lds ? api : by_lds;
-        if (blocks_per_cu < 1) blocks_per_cu = 1;
-    }
-    static const uint32_t exp_flags = getenv("NDZIP_HIP_EXP") ? static_cast<uint32_t>(atoi(getenv("NDZIP_HIP_EXP"))) : 0u;
-    static const int exp_bpc = getenv("NDZIP_HIP_BPC") ? atoi(getenv("NDZIP_HIP_BPC")) : 0;
-    uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(exp_bpc > 0 && exp_bpc < blocks_per_cu ? exp_bpc : blocks_per_cu);
-    if (grid > ntiles) grid = ntiles;
-    static const uint32_t exp_classes = getenv("NDZIP_HIP_CLASSES") ? static_cast<uint32_t>(atoi(getenv("NDZIP_HIP_CLASSES"))) : 0u;  // experiments
-    uint32_t num_classes = exp_classes >= 1 && exp_classes <= max_ticket_classes ? exp_classes : default_ticket_classes;
-    if (grid < num_classes) num_classes = 1;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), C::smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg, a.header,
-            static_cast<W *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16), num_classes, a.out_len,
-            a.len_extra, a.err, exp_flags, a.epoch);
-    return hipGetLastError();
+// ---- launchers ----------------------------------------------------------------------------------------------------------
+
+// Experiment knobs (tools/ablate.sh, tools/ab.sh) exist only in builds with -DNDZIP_EXP_KNOBS; the production library reads
+// no environment variable here and always runs the configuration below.
+struct launch_knobs {
+    uint32_t exp_flags = 0;  // passed to the kernel; ignored by it unless built with -DNDZIP_EXP_ABLATION / _PHASE_TIMING
+    int blocks_per_cu = 0;   // 0 = as many as fit
+    bool paired = true;      // 3D f32: tiles of two x-neighbours fetched as 128-byte rows
+};
+inline const launch_knobs &knobs() {
+    static const launch_knobs k = [] {
+        launch_knobs v;
+#ifdef NDZIP_EXP_KNOBS
+        if (const char *e = getenv("NDZIP_HIP_EXP")) v.exp_flags = static_cast<uint32_t>(atoi(e));
+        if (const char *e = getenv("NDZIP_HIP_BPC")) v.blocks_per_cu = atoi(e);
+        if (getenv("NDZIP_HIP_NO_PAIRED")) v.paired = false;
+#endif
+        return v;
+    }();
+    return k;
 }
 
-template<typename T, int Dims, bool Aligned>
-hipError_t launch_compress_profile(const compress_args &a) {
-    using C = tile_cfg<T, Dims>;
-    using W = typename C::W;
-    const uint32_t ntiles = (a.gg.nhc + C::K - 1) / C::K;
-    if (ntiles == 0) return hipSuccess;
-    // f32: deferred write-out with the encoded tile held in registers; f64 (twice the registers per plane set): the
-    // single-buffered kernel
-    constexpr bool use_db = sizeof(T) == 4;
-    constexpr uint32_t smem_bytes = C::smem_bytes;
-    void (*kernel)(const W *, const grid_geom, uint32_t *, W *, tile_desc *, uint32_t *, const uint32_t, uint32_t *, uint32_t, uint32_t *,
-            const uint32_t, const uint32_t);
-    bool paired = false;
-    if constexpr (use_db) {
-        if constexpr (Dims == 3 && Aligned) {
-            // tiles of two x-neighbours: needs an even hypercube count along x (then every tile 2m, 2m+1 is such a pair)
-            static const bool no_paired = getenv("NDZIP_HIP_NO_PAIRED") != nullptr;  // experiments only
-            paired = a.gg.g[2] % 2 == 0 && !no_paired;
-            kernel = paired ? compress_kernel_db<T, Dims, Aligned, true> : compress_kernel_db<T, Dims, Aligned, false>;
-        } else {
-            kernel = compress_kernel_db<T, Dims, Aligned>;
-        }
-    } else {
-        kernel = compress_kernel<T, Dims, Aligned>;
-    }
-    // f64: 256 work-items per hypercube, register-buffered (NDZIP_HIP_NARROW: the single-buffered 128-lane kernel, for
-    // experiments).  The same mapping for f32 -- one 16 KiB hypercube per tile, 96 VGPRs, 5 workgroups per CU -- is correct
-    // but slower than two hypercubes per 256 work-items: twice the tiles means twice the tickets, descriptors and
-    // look-backs (512^3: 0.284 vs 0.208 ms); build with -DNDZIP_EXP_WIDE_F32 and set NDZIP_HIP_WIDE_F32 to try it.
-    if constexpr (sizeof(T) == 8) {
-        static const bool narrow = getenv("NDZIP_HIP_NARROW") != nullptr;
-        if (!narrow) return launch_compress_wide<W, Dims, Aligned>(a);
-    }
-#ifdef NDZIP_EXP_WIDE_F32
-    if constexpr (sizeof(T) == 4) {
-        static const bool wide_f32 = getenv("NDZIP_HIP_WIDE_F32") != nullptr;
-        if (wide_f32) return launch_compress_wide<W, Dims, Aligned>(a);
-    }
-#endif
-    // persistent grid, fully resident: bounded by the occupancy query and by what the LDS alone admits
-    static int blocks_per_cu_of[2] = {0, 0};
-    int &blocks_per_cu = blocks_per_cu_of[paired ? 1 : 0];
-    if (blocks_per_cu == 0) {
-        int api = 0;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                static_cast<int>(smem_bytes));
-        if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel, C::threads, smem_bytes);
-        if (e != hipSuccess) return e;
-        const int by_lds = static_cast<int>((160u * 1024u) / smem_bytes);
-        blocks_per_cu = api < by_lds ? api : by_lds;
-        if (blocks_per_cu < 1) blocks_per_cu = 1;
-    }
-    static const uint32_t exp_flags = getenv("NDZIP_HIP_EXP") ? static_cast<uint32_t>(atoi(getenv("NDZIP_HIP_EXP"))) : 0u;
-    static const int exp_bpc = getenv("NDZIP_HIP_BPC") ? atoi(getenv("NDZIP_HIP_BPC")) : 0;
-    uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(exp_bpc > 0 && exp_bpc < blocks_per_cu ? exp_bpc : blocks_per_cu);
+// persistent grid, fully resident: workgroups per CU bounded by the occupancy query and by what the LDS alone admits
+template<typename Kernel>
+hipError_t persistent_blocks_per_cu(Kernel kernel, int threads, uint32_t smem_bytes, int *out) {
+    int api = 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            static_cast<int>(smem_bytes));
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel, threads, smem_bytes);
+    if (e != hipSuccess) return e;
+    const int by_lds = static_cast<int>((160u * 1024u) / smem_bytes);
+    int n = api < by_lds ? api : by_lds;
+    if (n < 1) n = 1;
+    const int cap = knobs().blocks_per_cu;
+    *out = cap > 0 && cap < n ? cap : n;
+    return hipSuccess;
+}
+
+// Scratch layout (fixed, whatever the extent): [16 x u64 experiment counters][ticket counters, one per 128 B][1 line:
+// workgroups done][descriptors].  Nothing is cleared per launch: descriptors carry the launch epoch, the kernel zeroes the
+// ticket counters on its way out (the owner of the scratch zeroes everything once).
+template<typename Kernel, typename W>
+hipError_t launch_persistent(Kernel kernel, int threads, uint32_t smem_bytes, int blocks_per_cu, uint32_t ntiles, const compress_args &a) {
+    uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(blocks_per_cu);
     if (grid > ntiles) grid = ntiles;
-    // scratch layout (fixed, whatever the extent): [16 x u64 experiment counters][max_ticket_classes ticket counters, one
-    // per 128 B][1 line: workgroups done][descriptors].  Nothing is cleared here: descriptors carry the launch epoch, the
-    // kernel zeroes the ticket counters on its way out (the owner of the scratch zeroes everything once).
+    // (a grid smaller than the class count would leave classes without a workgroup, i.e. tiles nobody draws)
+    const uint32_t num_classes = grid < ticket_classes ? 1u : ticket_classes;
+    const uint32_t exp_flags = knobs().exp_flags;
+#ifdef NDZIP_EXP_PHASE_TIMING
     if (exp_flags & 16u) {
         hipError_t e = hipMemsetAsync(a.desc, 0, 16 * sizeof(tile_desc), a.stream);
         if (e != hipSuccess) return e;
     }
-    static const uint32_t exp_classes = getenv("NDZIP_HIP_CLASSES") ? static_cast<uint32_t>(atoi(getenv("NDZIP_HIP_CLASSES"))) : 0u;  // experiments
-    uint32_t num_classes = exp_classes >= 1 && exp_classes <= max_ticket_classes ? exp_classes : default_ticket_classes;
-    if (grid < num_classes) num_classes = 1;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::threads), smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg,
-            a.header, static_cast<W *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16),
-            num_classes, a.out_len, a.len_extra, a.err, exp_flags, a.epoch);
-    if (exp_flags & 16u) {  // experiments only: dump the per-phase cycle totals of this launch
+#endif
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg, a.header,
+            static_cast<W *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16), num_classes, a.out_len,
+            a.len_extra, a.err, exp_flags, a.epoch);
+#ifdef NDZIP_EXP_PHASE_TIMING
+    if (exp_flags & 16u) {  // dump the per-phase cycle totals of this launch
         unsigned long long acc[16];
         (void) hipStreamSynchronize(a.stream);
         (void) hipMemcpy(acc, a.desc, sizeof acc, hipMemcpyDeviceToHost);
@@ -1130,7 +955,43 @@ hipError_t launch_compress_profile(const compress_args &a) {
             fprintf(stderr, "\n");
         }
     }
+#endif
     return hipGetLastError();
+}
+
+template<typename T, int Dims, bool Aligned>
+hipError_t launch_compress_profile(const compress_args &a) {
+    using W = typename word_of<T>::type;
+    if (a.gg.nhc == 0) return hipSuccess;
+    if constexpr (sizeof(T) == 8) {
+        // f64: 256 work-items per hypercube, one hypercube per tile (codec_kernels_wide.hpp)
+        using C = wide_cfg<W>;
+        auto kernel = compress_kernel_wide<W, Dims, Aligned>;
+        static int blocks_per_cu = 0;
+        if (blocks_per_cu == 0) {
+            hipError_t e = persistent_blocks_per_cu(kernel, C::threads, C::smem_bytes, &blocks_per_cu);
+            if (e != hipSuccess) return e;
+        }
+        return launch_persistent<decltype(kernel), W>(kernel, C::threads, C::smem_bytes, blocks_per_cu, a.gg.nhc, a);
+    } else {
+        // f32: 128 work-items per hypercube, two hypercubes per tile; in 3D with an even hypercube count along x every tile
+        // 2m, 2m+1 is a pair of x-neighbours and is fetched as 256 rows of 128 bytes
+        using C = tile_cfg<T, Dims>;
+        const uint32_t ntiles = (a.gg.nhc + C::K - 1) / C::K;
+        bool paired = false;
+        auto kernel = compress_kernel_db<T, Dims, Aligned, false>;
+        if constexpr (Dims == 3 && Aligned) {
+            paired = a.gg.g[2] % 2 == 0 && knobs().paired;
+            if (paired) kernel = compress_kernel_db<T, Dims, Aligned, true>;
+        }
+        static int blocks_per_cu_of[2] = {0, 0};
+        int &blocks_per_cu = blocks_per_cu_of[paired ? 1 : 0];
+        if (blocks_per_cu == 0) {
+            hipError_t e = persistent_blocks_per_cu(kernel, C::threads, C::smem_bytes, &blocks_per_cu);
+            if (e != hipSuccess) return e;
+        }
+        return launch_persistent<decltype(kernel), W>(kernel, C::threads, C::smem_bytes, blocks_per_cu, ntiles, a);
+    }
 }
 
 template<typename T, int Dims, bool Aligned>
@@ -1149,6 +1010,15 @@ template<typename T, int Dims, bool Aligned>
 hipError_t launch_debug_profile(int stage, const grid_geom &gg, uint32_t hc, const void *in, void *out, uint32_t *out_len,
         hipStream_t stream) {
     using W = typename word_of<T>::type;
+    if constexpr (sizeof(W) == 8) {
+        if (stage == debug_forward_transform || stage == debug_encode_residuals) {
+            using L = wide::layout<W>;
+            const uint32_t smem = L::cube_bytes + L::zero_bytes + 64;
+            hipLaunchKernelGGL((debug_stage_wide_kernel<Dims, Aligned>), dim3(1), dim3(wide::threads), smem, stream, stage, gg, hc,
+                    static_cast<const W *>(in), static_cast<W *>(out), out_len);
+            return hipGetLastError();
+        }
+    }
     using L = lds_layout<W>;
     const uint32_t smem = L::cube_bytes + L::zero_bytes + 64;
     hipLaunchKernelGGL((debug_stage_kernel<T, Dims, Aligned>), dim3(1), dim3(threads_per_hc), smem, stream, stage, gg, hc,

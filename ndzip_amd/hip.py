@@ -24,7 +24,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NDZIP_HIP_LIB") or os.path.join(_HERE, "libndzip_hip.so")  # override: A/B experiments only
+LIB_PATH = os.path.join(_HERE, "libndzip_hip.so")  # (A/B tooling assigns this before the first lib() call; no environment override)
 
 F32, F64 = 0, 1
 

@@ -5,7 +5,9 @@ the C ABI's stage entry points.  Mirrors the reference's stage tests (src/test/c
   GPU chunk decoding of a CPU-encoded cube                        :735-801
   inverse transform identical CPU vs GPU                          :889-947
 and the bit-transpose involution test of src/test/codec_generic_test.cc:65-81.
-Integer/bit work: the bar is bit-exact."""
+The stage entry points call the device functions the production kernels call (codec_launch.inl: debug_stage_kernel = the
+f32 encode stages of compress_kernel_db and the decode stages of decompress_kernel; debug_stage_wide_kernel = the f64
+encode stages of compress_kernel_wide).  Integer/bit work: the bar is bit-exact."""
 import numpy as np
 import pytest
 
@@ -89,7 +91,7 @@ def test_forward_transform_matches_oracle(hiplib, cuda_device, profile, aligned)
 
 
 @pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
-@pytest.mark.parametrize("pattern", ["sparse", "random", "zeros", "ones", "single_bits"])
+@pytest.mark.parametrize("pattern", ["sparse", "random", "zeros", "ones", "single_bits", "dense_chunks"])
 def test_residual_encoding_matches_oracle(hiplib, cuda_device, profile, pattern):
     import torch
 
@@ -106,6 +108,11 @@ def test_residual_encoding_matches_oracle(hiplib, cuda_device, profile, pattern)
         res = np.zeros(4096, dtype=wdt)
     elif pattern == "ones":
         res = np.full(4096, np.iinfo(wdt).max, dtype=wdt)
+    elif pattern == "dense_chunks":
+        # chunks that keep every plane next to empty ones: the 16-byte dense path at aligned and unaligned positions
+        res = random_bits((4096,), dtype, 8).view(wdt).copy()
+        res.reshape(-1, bits)[::3] = 0
+        res.reshape(-1, bits)[1::5, :] &= wdt(0xFF)
     else:
         res = (wdt(1) << (np.arange(4096, dtype=wdt) % wdt(bits))).astype(wdt)
         res[::3] = 0
