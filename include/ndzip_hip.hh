@@ -11,12 +11,16 @@
 //   make_offloader<T>(target::cuda, dims)                 offload.hh  make_hip_offloader<T>(dims)
 //   offloader<T>::compress / decompress                   offload.hh  hip_offloader<T>::compress / decompress
 //   compressed_length_bound<T>(extent)                     ndzip.hh   hip_compressed_length_bound<T>(extent)
+//   make_compressor<T>(dims, threads) / make_decompressor<T>  ndzip.hh make_hip_host_compressor<T>(dims) / _decompressor<T>
+//   compressor<T>::compress(data, extent, stream)           ndzip.hh  hip_host_compressor<T>   : compressor<T>
+//   decompressor<T>::decompress(stream, data, extent)       ndzip.hh  hip_host_decompressor<T> : decompressor<T>
 //   compressor<T, Dims> / decompressor<T, Dims>  (BASELINE north-star spelling; this reference revision only has
-//   the <T> + runtime-dims form)             hip_compressor_nd<T, Dims>, hip_decompressor_nd<T, Dims>
+//   the <T> + runtime-dims form)             hip_host_compressor_nd<T, Dims>, hip_host_decompressor_nd<T, Dims>
+//                                                                      (device pointers: hip_compressor_nd / hip_decompressor_nd)
 //
 // When built inside the reference tree, define NDZIP_HIP_WITH_REFERENCE_HEADERS before including this file: the
 // adaptor then uses ndzip::extent / compressor_requirements / offloader<T> from <ndzip/ndzip.hh>, <ndzip/offload.hh>
-// and hip_offloader<T> derives from ndzip::offloader<T>.  Stand-alone (the default) it ships minimal equivalents
+// hip_offloader<T> derives from ndzip::offloader<T>, hip_host_compressor<T> from ndzip::compressor<T>.  Stand-alone (the default) it ships minimal equivalents
 // with the same members.  Errors of the C ABI are rethrown as std::runtime_error (the reference throws
 // std::runtime_error for dimensionality mismatches and device failures: cuda_codec.inl:557-559, cuda_bits.cuh:165-169).
 #pragma once
@@ -107,6 +111,26 @@ class compressor_requirements {
   private:
     dim_type _dims = -1;
     index_type _max_num_hypercubes = 0;
+};
+
+// ndzip::compressor<T> / decompressor<T> (include/ndzip/ndzip.hh:227-247): the host-pointer plugin interface every CPU
+// back-end of the reference implements
+template<typename T>
+class compressor {
+  public:
+    using value_type = T;
+    using compressed_type = ndzip::compressed_type<T>;
+    virtual ~compressor() = default;
+    virtual index_type compress(const value_type *data, const extent &data_size, compressed_type *stream) = 0;
+};
+
+template<typename T>
+class decompressor {
+  public:
+    using value_type = T;
+    using compressed_type = ndzip::compressed_type<T>;
+    virtual ~decompressor() = default;
+    virtual index_type decompress(const compressed_type *stream, value_type *data, const extent &data_size) = 0;
 };
 
 // ndzip::offloader<T> (include/ndzip/offload.hh:8-34)
@@ -274,6 +298,74 @@ class hip_offloader final : public offloader<T> {
     dim_type _dims;
 };
 
+// ndzip::compressor<T> / decompressor<T> implemented on the GPU: what `make_compressor<T>(dims)` / `make_decompressor<T>(dims)`
+// (ndzip.hh:249-253, cpu_factory.cc:25-49) hand out, for callers written against the reference's plain host-pointer plugin
+// interface.  Same contract: host buffers in, stream words out, std::runtime_error on a dimensionality mismatch
+// (cpu_codec.inl:600-602).  decompress() has no length argument in this interface (ndzip.hh:245): the stream is sized from
+// its own header, which ndzip_hip_stream_words validates entry by entry against `stream_capacity_words` (default: the
+// format's bound for the extent, i.e. what the caller must have allocated for compress()).
+template<typename T>
+class hip_host_compressor final : public compressor<T> {
+  public:
+    using value_type = T;
+    using compressed_type = ndzip::compressed_type<T>;
+    explicit hip_host_compressor(dim_type dims) : _dims(dims) {
+        if (dims < 1 || dims > 3) throw std::runtime_error("Invalid dimensionality");  // common.hh:642
+    }
+    index_type compress(const value_type *data, const extent &data_size, compressed_type *stream) override {
+        if (data_size.dimensions() != _dims) throw std::runtime_error("data dimensionality does not match compressor dimensionality");
+        uint32_t words = 0;
+        hip_detail::check(ndzip_hip_offload_compress(hip_detail::dtype_of<T>(), _dims, data_size.begin(), data, stream, &words, nullptr));
+        return words;
+    }
+
+  private:
+    dim_type _dims;
+};
+
+template<typename T>
+class hip_host_decompressor final : public decompressor<T> {
+  public:
+    using value_type = T;
+    using compressed_type = ndzip::compressed_type<T>;
+    explicit hip_host_decompressor(dim_type dims) : _dims(dims) {
+        if (dims < 1 || dims > 3) throw std::runtime_error("Invalid dimensionality");
+    }
+    index_type decompress(const compressed_type *stream, value_type *data, const extent &data_size) override {
+        if (data_size.dimensions() != _dims) throw std::runtime_error("data dimensionality does not match decompressor dimensionality");
+        uint64_t capacity = 0;
+        hip_detail::check(ndzip_hip_compressed_length_bound(hip_detail::dtype_of<T>(), _dims, data_size.begin(), &capacity));
+        uint32_t length = 0, consumed = 0;
+        hip_detail::check(ndzip_hip_stream_words(hip_detail::dtype_of<T>(), _dims, data_size.begin(), stream, capacity, &length));
+        hip_detail::check(ndzip_hip_offload_decompress(hip_detail::dtype_of<T>(), _dims, data_size.begin(), stream, length, data, &consumed, nullptr));
+        return consumed;
+    }
+
+  private:
+    dim_type _dims;
+};
+
+// BASELINE.json's spelling compressor<T, Dims> / decompressor<T, Dims> for the host-pointer plugin interface
+template<typename T, dim_type Dims>
+class hip_host_compressor_nd final : public compressor<T> {
+  public:
+    static_assert(Dims >= 1 && Dims <= 3);
+    index_type compress(const T *data, const extent &data_size, compressed_type<T> *stream) override { return _impl.compress(data, data_size, stream); }
+
+  private:
+    hip_host_compressor<T> _impl{Dims};
+};
+
+template<typename T, dim_type Dims>
+class hip_host_decompressor_nd final : public decompressor<T> {
+  public:
+    static_assert(Dims >= 1 && Dims <= 3);
+    index_type decompress(const compressed_type<T> *stream, T *data, const extent &data_size) override { return _impl.decompress(stream, data, data_size); }
+
+  private:
+    hip_host_decompressor<T> _impl{Dims};
+};
+
 // Persistent, pipelined host-pointer offloader (ndzip_hip_offloader_*): device buffers, streams and codec handles are created
 // once for arrays up to `max_size`; `slots` jobs are in flight, so the H2D copy of one array, the kernels of the previous one
 // and the D2H copy of the one before overlap.  It IS an offloader<T> (compress / decompress run one job on slot 0 and wait),
@@ -366,6 +458,18 @@ std::unique_ptr<hip_decompressor<T>> make_hip_decompressor(dim_type dims, void *
 template<typename T>
 std::unique_ptr<offloader<T>> make_hip_offloader(dim_type dimensions) {
     return std::make_unique<hip_offloader<T>>(dimensions);
+}
+
+// drop-in for make_compressor<T>(dims, num_threads) / make_decompressor<T>(dims, num_threads) (ndzip.hh:249-253); the thread
+// count of the CPU back-ends has no meaning here and is accepted for signature compatibility
+template<typename T>
+std::unique_ptr<compressor<T>> make_hip_host_compressor(dim_type dims, unsigned /* num_threads */ = 0) {
+    return std::make_unique<hip_host_compressor<T>>(dims);
+}
+
+template<typename T>
+std::unique_ptr<decompressor<T>> make_hip_host_decompressor(dim_type dims, unsigned /* num_threads */ = 0) {
+    return std::make_unique<hip_host_decompressor<T>>(dims);
 }
 
 template<typename T>

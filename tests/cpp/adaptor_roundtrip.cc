@@ -34,6 +34,44 @@ int run(ndzip::dim_type dims, ndzip::index_type n) {
     return threw ? 0 : 4;
 }
 
+// the plain plugin interface (ndzip.hh:227-253): what a caller of make_compressor<T>(dims) / make_decompressor<T>(dims) does
+template<typename T, ndzip::dim_type Dims>
+int run_plugin(ndzip::index_type n) {
+    const auto size = ndzip::extent::broadcast(Dims, n);
+    std::vector<T> input(ndzip::num_elements(size));
+    std::minstd_rand gen(11);
+    std::uniform_real_distribution<T> dist;
+    for (auto &v : input) v = dist(gen);
+    std::unique_ptr<ndzip::compressor<T>> comp = ndzip::make_hip_host_compressor<T>(Dims);
+    std::unique_ptr<ndzip::decompressor<T>> decomp = ndzip::make_hip_host_decompressor<T>(Dims);
+    std::vector<ndzip::compressed_type<T>> stream(ndzip::hip_compressed_length_bound<T>(size));
+    const auto words = comp->compress(input.data(), size, stream.data());
+    std::vector<T> output(input.size());
+    if (decomp->decompress(stream.data(), output.data(), size) != words) return 1;
+    if (std::memcmp(input.data(), output.data(), input.size() * sizeof(T)) != 0) return 2;
+    // the <T, Dims> spelling produces the same stream
+    ndzip::hip_host_compressor_nd<T, Dims> comp_nd;
+    std::vector<ndzip::compressed_type<T>> stream2(stream.size());
+    if (comp_nd.compress(input.data(), size, stream2.data()) != words) return 3;
+    if (std::memcmp(stream.data(), stream2.data(), words * sizeof(stream[0])) != 0) return 3;
+    ndzip::hip_host_decompressor_nd<T, Dims> decomp_nd;
+    std::fill(output.begin(), output.end(), T{});
+    if (decomp_nd.decompress(stream.data(), output.data(), size) != words) return 4;
+    if (std::memcmp(input.data(), output.data(), input.size() * sizeof(T)) != 0) return 4;
+    bool threw = false;
+    try {
+        comp->compress(input.data(), ndzip::extent::broadcast(Dims == 3 ? 2 : Dims + 1, 4), stream.data());
+    } catch (const std::runtime_error &) { threw = true; }
+    if (!threw) return 5;
+    // a corrupt header is an exception, not a device fault
+    reinterpret_cast<uint32_t *>(stream.data())[0] = 0xfffffff0u;
+    threw = false;
+    try {
+        decomp->decompress(stream.data(), output.data(), size);
+    } catch (const std::runtime_error &) { threw = true; }
+    return threw ? 0 : 6;
+}
+
 // several arrays in flight through the persistent offloader, pinned buffers; every stream must equal the one-shot offloader's
 template<typename T>
 int run_pipelined(ndzip::dim_type dims, ndzip::index_type n) {
@@ -85,6 +123,12 @@ int main() {
     rc |= run<double>(3, 16 * 4 - 1) << 20;
     rc |= run_pipelined<float>(3, 16 * 4 - 1) << 24;
     rc |= run_pipelined<double>(2, 64 * 3 + 5) << 26;
+    int rc2 = 0;
+    rc2 |= run_plugin<float, 1>(4096 * 2 + 7);
+    rc2 |= run_plugin<float, 3>(16 * 3 + 1) << 4;
+    rc2 |= run_plugin<double, 2>(64 * 2 + 3) << 8;
+    if (rc2) std::printf("plugin interface FAILED 0x%x\n", rc2);
+    rc |= rc2 << 28;
     std::printf(rc ? "FAILED 0x%x\n" : "adaptor round trips ok\n", rc);
     return rc != 0;
 }

@@ -6,3 +6,9 @@
 #include <ndzip_hip.hh>
 template std::unique_ptr<ndzip::offloader<float>> ndzip::make_hip_offloader<float>(ndzip::dim_type);
 template std::unique_ptr<ndzip::offloader<double>> ndzip::make_hip_offloader<double>(ndzip::dim_type);
+// ... and the plain plugin interface: what the reference's make_compressor<T> / make_decompressor<T> (cpu_factory.cc:25-49) would
+// return for a HIP target
+template std::unique_ptr<ndzip::compressor<float>> ndzip::make_hip_host_compressor<float>(ndzip::dim_type, unsigned);
+template std::unique_ptr<ndzip::compressor<double>> ndzip::make_hip_host_compressor<double>(ndzip::dim_type, unsigned);
+template std::unique_ptr<ndzip::decompressor<float>> ndzip::make_hip_host_decompressor<float>(ndzip::dim_type, unsigned);
+template std::unique_ptr<ndzip::decompressor<double>> ndzip::make_hip_host_decompressor<double>(ndzip::dim_type, unsigned);

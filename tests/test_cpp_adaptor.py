@@ -33,6 +33,8 @@ def test_integration_factory_unit_compiles_in_the_reference_tree(tmp_path):
     syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True, check=True).stdout
     assert "ndzip::make_hip_offloader<float>(int)" in syms or "make_hip_offloader<float>" in syms
     assert "make_hip_offloader<double>" in syms
+    # hip_host_compressor<T> IS an ndzip::compressor<T> of the reference's own header
+    assert "make_hip_host_compressor<float>" in syms and "make_hip_host_decompressor<double>" in syms
 
 
 @pytest.mark.gpu
@@ -45,5 +47,20 @@ def test_adaptor_roundtrip_on_gpu(tmp_path):
                         "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "adaptor round trips ok" in r.stdout
+
+
+def test_adaptor_roundtrip_on_the_cpu_model(tmp_path):
+    """The same reference-style program, linked against the wave64 functional model of the library (tests/wavesim, test
+    infrastructure): the adaptor classes, the C ABI behind them and the kernels' logic, without a GPU."""
+    from tests.wavesim import build as simbuild
+
+    lib = simbuild.build()
+    exe = str(tmp_path / "adaptor_rt_model")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe, lib, "-Wl,-rpath," + os.path.dirname(lib)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "adaptor round trips ok" in r.stdout
