@@ -1,22 +1,36 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the ndzip block encode/decode path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run, one
-rank per GPU over RCCL).  One "step" = compress the synthetic grid, then decompress it again, with the input
-already resident in HBM.  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run, one rank per
+GPU over RCCL).  One "step" = one pass of the hot path over the synthetic grid, inputs already resident in HBM: compress,
+then decompress (`--compress-only` / `--decompress-only`: that half).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): 3D float32 512x512x512 synthetic turbulence per GPU (SURVEY.md Appendix B
-generator, seed 1, noise_mask 0xff).  At N GPUs the grid is (512*N) x 512 x 512 cut into N z-slabs (weak scaling:
-per-GPU work fixed); the only exchange is the RCCL all-gather of one length per rank + the header all-gather
-(ndzip_amd/sharded.py).  `value` = uncompressed bytes that went through compress plus uncompressed bytes that
-came out of decompress, over all ranks, divided by the wall time of the K timed steps (max over ranks).
+Workloads (`--config`, BASELINE.json `configs`):
+  2 (default)  3D float32 512x512x512 per GPU -- the configuration the metric is quoted on.  At N GPUs the grid is
+               (512 N) x 512 x 512 cut into N z-slabs: weak scaling, per-GPU work fixed.
+  1            1D float32 16 Mi elements per GPU (the reference's CPU-runnable case; its `-e cpu -T 1` figure is the
+               `cpu_reference_serial_cfg1` leg, reported with every run).
+  3            2D float64 8192 x 8192 per GPU (64-bit transpose path).
+  4            3D float32, z-slabs of 256 x 1024 x 1024 per GPU: at N = 8 exactly 2048 x 1024 x 1024 (8 GiB) sharded with
+               the RCCL offset scan; fewer GPUs take fewer slabs (weak scaling).
+  5            3D float64, z-slabs of 128 x 1024 x 1024 per GPU, decompress-only: at N = 8 exactly 1024^3 (8 GiB).
+  16gib        3D float64 2048 x 1024 x 1024 = 16 GiB (2^31 elements, the largest grid the format's uint32 counts allow for
+               this target) split over the N ranks: STRONG scaling, the ">= 6x at 8 GPUs over 1 GPU" line of north_star.
+`--shape/--dtype` override the per-GPU slab.  The only exchange at N > 1 is the all-gather of one length per rank + the
+header all-gather (ndzip_amd/sharded.py); bodies stay resident.
+
+`value` = uncompressed bytes that went through compress plus uncompressed bytes that came out of decompress, over all
+ranks, divided by the wall time of the K timed steps (barrier + synchronize on both sides, max over ranks).
 
 Extra objects:
-  roofline      dominant kernel = compress_kernel_db<float,3> (compress_kernel_wide<u64,D> for float64 runs): algorithmic bytes (raw in + stream out) per launch over
-                the HIP-event duration of the launch on the stream it runs on; peak 8 TB/s (HBM3E spec).
-  cpu_baseline  this repo's OpenMP port of the reference CPU path (oracle/, bit-exact with the compiled
-                reference) timed on the host cores of the same box on the same grid; plus the genuine reference
-                serial path (oracle/_ref) on a z-slab sample as `cpu_reference_serial`.
+  roofline      the dominant kernel of the step (compress_kernel_db<float,D> / compress_kernel_wide<u64,D>; decompress_kernel
+                for decompress-only runs): algorithmic bytes (raw + stream) per launch over the HIP-event
+                duration of the launch on the stream it runs on; peak 8 TB/s (HBM3E spec).  The other kernel rides along.
+  cpu_baseline  the GENUINE reference CPU codec (oracle/_ref, compiled from /root/reference; serial path -- its OpenMP path
+                needs Boost, absent here) on the host's physical cores, one independent block of the same grid per thread;
+                median of several repetitions with best and spread; value null when best/median > 2 (a disturbed host).
+                Falls back to the repo's OpenMP port (kind "port") where oracle/_ref is absent.  The port, the serial
+                reference on a sample of the workload and on config 1's 1D 16 Mi array ride along as extra legs.
 """
 from __future__ import annotations
 
@@ -33,43 +47,182 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0        # measured float4 copy ceiling from the same guide
 
+CONFIGS = {
+    # name: (description, dtype, per-GPU slab or None, global extent for strong scaling or None, mode)
+    "1": ("BASELINE configs[0]: 1D float32 16 Mi", "float32", (1 << 24,), None, "both"),
+    "2": ("BASELINE configs[1]: 3D float32 512x512x512", "float32", (512, 512, 512), None, "both"),
+    "3": ("BASELINE configs[2]: 2D float64 8192x8192", "float64", (8192, 8192), None, "both"),
+    "4": ("BASELINE configs[3]: 3D float32 2048x1024x1024 over 8 GPUs = z-slabs of 256x1024x1024", "float32", (256, 1024, 1024), None, "both"),
+    "5": ("BASELINE configs[4]: 3D float64 1024^3 over 8 GPUs = z-slabs of 128x1024x1024, decompress-only", "float64", (128, 1024, 1024), None,
+          "decompress"),
+    "16gib": ("north_star scaling target: 3D float64 2048x1024x1024 = 16 GiB, strong scaling", "float64", None, (2048, 1024, 1024), "both"),
+}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--shape", type=str, default="512,512,512", help="per-GPU slab (dimension 0 is multiplied by --gpus)")
-    ap.add_argument("--dtype", type=str, default="float32", choices=["float32", "float64"])
+    ap.add_argument("--config", type=str, default="2", choices=sorted(CONFIGS), help="BASELINE.json workload (see the module docstring)")
+    ap.add_argument("--shape", type=str, default=None, help="override: per-GPU slab (dimension 0 is multiplied by --gpus)")
+    ap.add_argument("--dtype", type=str, default=None, choices=["float32", "float64"])
     ap.add_argument("--noise-mask", type=lambda s: int(s, 0), default=0xFF)
     ap.add_argument("--smooth", action="store_true", help="highly compressible bookend (two low-frequency octaves)")
     ap.add_argument("--data", type=str, default="synthetic", choices=["synthetic", "random", "zeros"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--compress-only", action="store_true", help="timing experiments: skip the decompress half of a step")
+    ap.add_argument("--compress-only", action="store_true", help="a step is the compress half only")
+    ap.add_argument("--decompress-only", action="store_true", help="a step is the decompress half only (the grid is compressed once, untimed)")
+    ap.add_argument("--lib", type=str, default=None, help="A/B tooling: load this build of the library instead of ndzip_amd/libndzip_hip.so")
     return ap.parse_args()
 
 
-def cpu_baseline(host_grid, dims):
-    """OpenMP port on the host cores + the genuine serial reference on a bounded sample (rank 0, N = 1 only).
-    The port is timed in a subprocess (oracle/timing.py) so its OpenMP team is pinned and spinning; medians over up to
-    12 repetitions of the full grid (about 20 s at the most)."""
+# ---- CPU legs (rank 0, N = 1 only; bounded samples; the checker's code is timed here, never shipped) -------------------------
+
+def physical_cores() -> int:
     import subprocess
-    import tempfile
+
+    cores = os.cpu_count() or 1
+    try:  # physical cores = the reference's default thread count (cpu_factory.cc:8-9)
+        txt = subprocess.run(["lscpu", "-p=CORE,SOCKET"], capture_output=True, text=True).stdout
+        phys = len({l for l in txt.splitlines() if l and not l.startswith("#")})
+        if phys > 0:
+            cores = min(cores, phys)
+    except Exception:
+        pass
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return max(1, cores)
+
+
+def _blocks(shape, threads):
+    """Cut `shape` into up to `threads` blocks of whole hypercubes: dimension 0 first, then dimension 1.  Every block is an
+    independent ndzip array.  -> list of tuples of slices"""
+    side = {1: 4096, 2: 64, 3: 16}[len(shape)]
+    g0 = shape[0] // side
+    n0 = max(1, min(threads, g0))
+    n1 = 1
+    if len(shape) >= 2:
+        g1 = shape[1] // side
+        n1 = max(1, min(threads // n0, g1))
+    out = []
+    for i in range(n0):
+        a, b = i * g0 // n0 * side, (i + 1) * g0 // n0 * side
+        if len(shape) == 1:
+            out.append((slice(a, b),))
+            continue
+        for j in range(n1):
+            c, d = j * g1 // n1 * side, (j + 1) * g1 // n1 * side
+            out.append((slice(a, b), slice(c, d)))
+    return [s for s in out if all(x.stop > x.start for x in s)]
+
+
+def _spread_stats(times, nbytes):
+    import numpy as np
+
+    med, best = float(np.median(times)), float(min(times))
+    return nbytes / med / 1e9, nbytes / best / 1e9, med / best
+
+
+def cpu_reference_blocks(host_grid, cores, budget_s):
+    """The genuine reference serial codec (oracle/_ref), one independent block of the grid per thread, all threads at once:
+    what the host's cores give a caller of the reference without its Boost-dependent OpenMP back-end.  ctypes releases the
+    GIL around the calls; every buffer is first touched by the thread that uses it.  Repeated until the budget is spent
+    (at least 3, at most 15 repetitions); per repetition the wall time of the slowest thread counts."""
+    import threading
 
     import numpy as np
 
     from oracle import oracle
 
-    out = {}
-    cores = os.cpu_count() or 1
-    try:  # physical cores = the reference's default thread count (cpu_factory.cc:8-9)
-        txt = subprocess.run(["lscpu", "-p=CORE,SOCKET"], capture_output=True, text=True).stdout
-        phys_cores = len({l for l in txt.splitlines() if l and not l.startswith("#")})
-        if phys_cores > 0:
-            cores = phys_cores
-    except Exception:
-        pass
+    blocks = _blocks(host_grid.shape, cores)
+    threads = len(blocks)
+    wdt = np.uint32 if host_grid.itemsize == 4 else np.uint64
+    max_reps = 15
+    tc = np.zeros((threads, max_reps))
+    td = np.zeros((threads, max_reps))
+    ok = [False] * threads
+    stop = [False]
+    bar = threading.Barrier(threads + 1, timeout=180)  # (timeout + abort: a failing worker must not hang the benchmark)
+
+    def work(i):
+        try:
+            local = np.array(host_grid[blocks[i]], copy=True)   # first touch on this thread
+            s = oracle.ref_compress(local)                       # warm code and buffers
+            back, _ = oracle.ref_decompress(s, local.dtype, local.shape)
+            ok[i] = bool(np.array_equal(back.view(wdt).reshape(-1), local.view(wdt).reshape(-1)))
+            r = 0
+            while True:
+                bar.wait()
+                if stop[0]:
+                    break
+                t0 = time.perf_counter()
+                s = oracle.ref_compress(local)
+                t1 = time.perf_counter()
+                bar.wait()
+                t2 = time.perf_counter()
+                oracle.ref_decompress(s, local.dtype, local.shape)
+                t3 = time.perf_counter()
+                tc[i, r], td[i, r] = t1 - t0, t3 - t2
+                r += 1
+                bar.wait()
+        except Exception:
+            bar.abort()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    wall_c, wall_d = [], []
+    t_begin = time.perf_counter()
+    while len(wall_c) < max_reps and (len(wall_c) < 3 or time.perf_counter() - t_begin < budget_s):
+        bar.wait()
+        t0 = time.perf_counter()
+        bar.wait()
+        t1 = time.perf_counter()
+        bar.wait()
+        t2 = time.perf_counter()
+        wall_c.append(t1 - t0)
+        wall_d.append(t2 - t1)
+    stop[0] = True
+    bar.wait()
+    for t in ts:
+        t.join()
+    nbytes = sum(host_grid[b].size for b in blocks) * host_grid.itemsize
+    c_med, c_best, c_spread = _spread_stats(wall_c, nbytes)
+    d_med, d_best, d_spread = _spread_stats(wall_d, nbytes)
+    stable = c_spread <= 2.0 and d_spread <= 2.0
+    leg = {
+        "value": round(2.0 / (1.0 / c_med + 1.0 / d_med), 3) if stable else None,
+        "unit": "GB/s",
+        "cores": threads,
+        "kind": "reference",
+        "sample": f"{threads} blocks of the {'x'.join(map(str, host_grid.shape))} {host_grid.dtype} grid ({nbytes >> 20} MiB in all), each compressed "
+                  f"and decompressed as its own array by the reference's serial CPU codec (oracle/_ref, compiled from the reference "
+                  f"sources) on its own thread, all threads at once; median of {len(wall_c)} repetitions, wall time of the slowest thread",
+        "compress_GBps": round(c_med, 3),
+        "decompress_GBps": round(d_med, 3),
+        "compress_GBps_best": round(c_best, 3),
+        "decompress_GBps_best": round(d_best, 3),
+        "median_over_best": [round(c_spread, 2), round(d_spread, 2)],
+        "roundtrip_ok": all(ok),
+    }
+    if not stable:
+        leg["reason"] = "best and median repetition differ by more than 2x: the host was disturbed, no value reported"
+    return leg
+
+
+def cpu_port_openmp(host_grid, cores, budget_s):
+    """The repo's OpenMP restatement of the reference CPU codec (oracle/ndzip_oracle.c, bit-exact with the compiled reference),
+    timed in a subprocess (oracle/timing.py) so its thread team is pinned and spinning."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     path = os.path.join(shm, f"ndzip_bench_grid_{os.getpid()}.npy")
     np.save(path, host_grid)
@@ -77,126 +230,111 @@ def cpu_baseline(host_grid, dims):
         # close binding on physical cores was the stable setting on the 2 x 64-core host (tools/cpu_env_probe.sh)
         env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
         env.pop("OMP_WAIT_POLICY", None)
-        r = subprocess.run([sys.executable, "-m", "oracle.timing", path, str(cores), "20"], capture_output=True, text=True, cwd=ROOT, env=env,
-                           timeout=300)
+        r = subprocess.run([sys.executable, "-m", "oracle.timing", path, str(cores), str(budget_s)], capture_output=True, text=True, cwd=ROOT,
+                           env=env, timeout=300)
         t = json.loads(r.stdout.strip().splitlines()[-1])
     finally:
         os.remove(path)
     c, d = t["compress_GBps_median"], t["decompress_GBps_median"]
-    out["cpu_baseline"] = {
-        "value": round(2.0 / (1.0 / c + 1.0 / d), 3),
+    spread = [t["compress_GBps_best"] / c, t["decompress_GBps_best"] / d]
+    stable = max(spread) <= 2.0
+    leg = {
+        "value": round(2.0 / (1.0 / c + 1.0 / d), 3) if stable else None,
         "unit": "GB/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"full {'x'.join(map(str, host_grid.shape))} {host_grid.dtype} grid, median of {t['reps']} reps compress+decompress, OpenMP port "
-                  f"of the reference CPU codec (oracle/ndzip_oracle.c), threads pinned to physical cores",
+        "sample": f"{'x'.join(map(str, host_grid.shape))} {host_grid.dtype} grid, median of {t['reps']} reps compress+decompress, OpenMP port of the "
+                  f"reference CPU codec (oracle/ndzip_oracle.c: scalar C, the reference is AVX2), threads pinned to physical cores",
         "compress_GBps": round(c, 3),
         "decompress_GBps": round(d, 3),
         "compress_GBps_best": round(t["compress_GBps_best"], 3),
         "decompress_GBps_best": round(t["decompress_GBps_best"], 3),
+        "median_over_best": [round(x, 2) for x in spread],
         "roundtrip_ok": t["roundtrip_ok"],
     }
-    if oracle.have_ref():
-        sample = host_grid[: max(16, host_grid.shape[0] // 8)]  # 64 z-planes of the 512^3 grid = 64 MiB
-        oracle.ref_compress(sample[:16])
-        t0 = time.perf_counter()
-        s = oracle.ref_compress(sample)
-        t1 = time.perf_counter()
-        oracle.ref_decompress(s, sample.dtype, sample.shape)
-        t2 = time.perf_counter()
-        out["cpu_reference_serial"] = {
-            "value": round(2 * sample.nbytes / (t2 - t0) / 1e9, 3),
-            "unit": "GB/s",
-            "cores": 1,
-            "kind": "reference",
-            "sample": f"first {sample.shape[0]} z-planes ({sample.nbytes >> 20} MiB), reference serial CPU path compiled from /root/reference (oracle/_ref)",
-            "compress_GBps": round(sample.nbytes / (t1 - t0) / 1e9, 3),
-            "decompress_GBps": round(sample.nbytes / (t2 - t1) / 1e9, 3),
-        }
-    if oracle.have_ref() and host_grid.ndim == 3 and host_grid.shape[0] >= 32:
-        try:
-            out["cpu_reference_slabs"] = cpu_reference_slabs(host_grid, cores)
-        except Exception as e:  # a reported extra, never fatal
-            out["cpu_reference_slabs"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
-    return out
+    if not stable:
+        leg["reason"] = "best and median repetition differ by more than 2x: the host was disturbed, no value reported"
+    return leg
 
 
-def cpu_reference_slabs(host_grid, cores):
-    """The genuine reference serial compressor (oracle/_ref), one z-slab per thread: what a caller of the reference gets from the
-    host's cores without the reference's OpenMP back-end (which needs Boost and does not build here).  Every slab is an
-    independent ndzip stream of 16 k z-planes; ctypes releases the GIL around the calls; buffers are first touched by the
-    thread that uses them."""
-    import threading
-
+def cpu_reference_serial(sample, what):
+    """The genuine reference serial path, one thread (the reference tool's `-e cpu -T 1`, src/compress/compress.cc:103-107)."""
     import numpy as np
 
     from oracle import oracle
 
-    planes = host_grid.shape[0]
-    threads = max(1, min(cores, planes // 16))
-    per = (planes // threads) // 16 * 16
-    threads = min(threads, planes // per)
-    slabs = [host_grid[i * per: (i + 1) * per] for i in range(threads)]
-    tc = [0.0] * threads
-    td = [0.0] * threads
-    ok = [False] * threads
-    # (timeouts + abort: a failing worker must not leave the others, or the benchmark, waiting)
-    start = threading.Barrier(threads + 1, timeout=120)
-    mid = threading.Barrier(threads + 1, timeout=120)
-    end = threading.Barrier(threads + 1, timeout=120)
-    wdt = np.uint32 if host_grid.itemsize == 4 else np.uint64
-
-    def work(i):
-        try:
-            local = np.array(slabs[i], copy=True)                 # first touch on this thread
-            oracle.ref_compress(local[:16])                        # warm the code
-            start.wait()
-            t0 = time.perf_counter()
-            s = oracle.ref_compress(local)
-            tc[i] = time.perf_counter() - t0
-            mid.wait()
-            t0 = time.perf_counter()
-            back, _ = oracle.ref_decompress(s, local.dtype, local.shape)
-            td[i] = time.perf_counter() - t0
-            end.wait()
-            ok[i] = bool(np.array_equal(back.view(wdt).reshape(-1), local.view(wdt).reshape(-1)))
-        except Exception:
-            for b in (start, mid, end):
-                b.abort()
-
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
-    for t in ts:
-        t.start()
-    start.wait()
-    t0 = time.perf_counter()
-    mid.wait()
-    t1 = time.perf_counter()
-    end.wait()
-    t2 = time.perf_counter()
-    for t in ts:
-        t.join()
-    nbytes = threads * per * host_grid[0].nbytes
+    oracle.ref_decompress(oracle.ref_compress(sample), sample.dtype, sample.shape)  # untimed: code and pages warm
+    tc, td = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        s = oracle.ref_compress(sample)
+        t1 = time.perf_counter()
+        back, _ = oracle.ref_decompress(s, sample.dtype, sample.shape)
+        t2 = time.perf_counter()
+        tc.append(t1 - t0)
+        td.append(t2 - t1)
+    wdt = np.uint32 if sample.itemsize == 4 else np.uint64
+    c, d = sample.nbytes / float(np.median(tc)) / 1e9, sample.nbytes / float(np.median(td)) / 1e9
     return {
-        "value": round(2 * nbytes / (t2 - t0) / 1e9, 3),
+        "value": round(2.0 / (1.0 / c + 1.0 / d), 3),
         "unit": "GB/s",
-        "cores": threads,
+        "cores": 1,
         "kind": "reference",
-        "sample": f"{threads} z-slabs of {per} planes ({nbytes >> 20} MiB in all), each compressed and decompressed by the reference's serial CPU "
-                  f"path (oracle/_ref) on its own thread, wall time of the slowest",
-        "compress_GBps": round(nbytes / (t1 - t0) / 1e9, 3),
-        "decompress_GBps": round(nbytes / (t2 - t1) / 1e9, 3),
-        "roundtrip_ok": all(ok),
+        "sample": f"{what} ({sample.nbytes >> 20} MiB), reference serial CPU path compiled from the reference sources (oracle/_ref), median of 3",
+        "compress_GBps": round(c, 3),
+        "decompress_GBps": round(d, 3),
+        "ratio": round(len(s) * s.itemsize / sample.nbytes, 4),
+        "roundtrip_ok": bool(np.array_equal(back.view(wdt).reshape(-1), sample.view(wdt).reshape(-1))),
     }
 
 
+def cpu_legs(host_grid, budget_s):
+    """-> dict of the CPU objects of the JSON line.  `host_grid`: a bounded sample of the benchmarked workload."""
+    import numpy as np
+
+    from ndzip_amd.synth import synth_numpy
+    from oracle import oracle
+
+    out = {}
+    cores = physical_cores()
+
+    def guarded(name, fn, kind):
+        try:
+            out[name] = fn()
+        except Exception as e:  # a reported extra must never cost the GPU number
+            out[name] = {"value": None, "unit": "GB/s", "cores": 0, "kind": kind, "sample": f"failed: {type(e).__name__}: {e}"}
+
+    if oracle.have_ref():
+        guarded("cpu_baseline", lambda: cpu_reference_blocks(host_grid, cores, budget_s), "reference")
+        guarded("cpu_port_openmp", lambda: cpu_port_openmp(host_grid, cores, min(budget_s, 8.0)), "port")
+        first = host_grid[: max(16, host_grid.shape[0] // 8)] if host_grid.ndim == 3 else host_grid[: max(1, host_grid.shape[0] // 8)]
+        guarded("cpu_reference_serial", lambda: cpu_reference_serial(np.ascontiguousarray(first), f"first {first.shape[0]} rows of dimension 0 of the workload"),
+                "reference")
+        cfg1 = synth_numpy((1 << 24,), np.float32, seed=3, noise_mask=0xFF)
+        guarded("cpu_reference_serial_cfg1",
+                lambda: cpu_reference_serial(cfg1, "BASELINE configs[0]: 1D float32 16 Mi elements (Appendix-B generator seed 3, noise_mask 0xff)"),
+                "reference")
+    else:
+        guarded("cpu_baseline", lambda: cpu_port_openmp(host_grid, cores, budget_s), "port")
+    return out
+
+
+# ---- the GPU benchmark ------------------------------------------------------------------------------------------------------
+
 def main():
     args = parse_args()
+    if args.compress_only and args.decompress_only:
+        raise SystemExit("--compress-only and --decompress-only exclude each other")
     import numpy as np
     import torch
     import torch.distributed as dist
 
+    from ndzip_amd import hip
+
+    if args.lib:
+        hip.LIB_PATH = os.path.abspath(args.lib)
     import ndzip_amd
-    from ndzip_amd.sharded import ShardedCodec
+    from ndzip_amd.sharded import ShardedCodec, plan_shards
     from ndzip_amd.synth import synth_torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,19 +357,28 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    per_gpu = tuple(int(x) for x in args.shape.split(","))
-    dims = len(per_gpu)
-    np_dtype = np.dtype(args.dtype)
+    desc, cfg_dtype, cfg_slab, cfg_global, cfg_mode = CONFIGS[args.config]
+    np_dtype = np.dtype(args.dtype or cfg_dtype)
+    if args.shape:
+        per_gpu = tuple(int(x) for x in args.shape.split(","))
+        global_extent = (per_gpu[0] * world,) + per_gpu[1:]
+        scaling, desc = "weak", f"custom slab {args.shape}"
+    elif cfg_global is not None:
+        global_extent = cfg_global
+        scaling = "strong"
+    else:
+        per_gpu = cfg_slab
+        global_extent = (per_gpu[0] * world,) + per_gpu[1:]
+        scaling = "weak"
+    mode = "compress" if args.compress_only else "decompress" if (args.decompress_only or cfg_mode == "decompress") else "both"
+    dims = len(global_extent)
     t_dtype = torch.float32 if np_dtype == np.float32 else torch.float64
-    global_extent = (per_gpu[0] * world,) + per_gpu[1:]
     codec = ShardedCodec(np_dtype, global_extent, rank, world, device)
     shard = codec.shard
 
     # ---- synthetic input, generated directly in HBM (identical bits on every machine) ------------------------------
     if args.data == "synthetic":
         # the slab's values depend on the GLOBAL coordinates: generate with the global linear offset
-        full = None
-        n_local = int(np.prod(shard.extent))
         local = synth_slab(synth_torch, global_extent, shard, t_dtype, device, args.noise_mask, args.smooth)
     elif args.data == "random":
         g = torch.Generator(device=device)
@@ -244,11 +391,17 @@ def main():
     out = torch.empty_like(local)
     raw_bytes_local = local.numel() * local.element_size()
 
+    if mode == "decompress":  # the stream that every timed step decodes
+        codec.compress(local)
+        torch.cuda.synchronize()
+        codec.check()
+
     def step(ev=None):
-        # ev[0..1] bracket the compress launch (descriptor memset + compress kernel [+ border kernel]) on the stream it
-        # runs on, ev[2..3] the decompress launch; the offset / header exchange of the N > 1 path lies between them
-        codec.compress(local, kernel_events=(ev[0], ev[1]) if ev else None)
-        if not args.compress_only:
+        # ev[0..1] bracket the compress launch (compress kernel [+ border kernel]) on the stream it runs on, ev[2..3] the
+        # decompress launch; the offset / header exchange of the N > 1 path lies between them
+        if mode != "decompress":
+            codec.compress(local, kernel_events=(ev[0], ev[1]) if ev else None)
+        if mode != "compress":
             if ev:
                 ev[2].record()
             codec.decompress(out)
@@ -258,8 +411,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if not args.compress_only:
-        codec.check()
+    codec.check()
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     if world > 1:
@@ -273,19 +425,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if not args.compress_only:
-        codec.check()
+    codec.check()
 
-    t_comp = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps * 1e-3   # seconds per launch
-    t_decomp = 1e-9 if args.compress_only else sum(e[2].elapsed_time(e[3]) for e in events) / args.steps * 1e-3
+    t_comp = None if mode == "decompress" else sum(e[0].elapsed_time(e[1]) for e in events) / args.steps * 1e-3   # seconds per launch
+    t_decomp = None if mode == "compress" else sum(e[2].elapsed_time(e[3]) for e in events) / args.steps * 1e-3
 
-    # ---- verification (outside the timed region): round trip is bit-exact; stream hash for the record ---------------
+    # ---- verification (outside the timed region): round trip is bit-exact ------------------------------------------
     body_len = int(codec.body_len.cpu()[0]) & 0xFFFFFFFF
     ok = True
-    if not args.no_verify and not args.compress_only:
-        ok = bool(torch.equal(out.view(torch.int32 if np_dtype == np.float32 else torch.int64),
-                              local.view(torch.int32 if np_dtype == np.float32 else torch.int64)))
-    stats = torch.tensor([elapsed, t_comp, t_decomp, float(body_len), float(ok)], dtype=torch.float64, device=device)
+    if not args.no_verify and mode != "compress":
+        it = torch.int32 if np_dtype == np.float32 else torch.int64
+        ok = bool(torch.equal(out.view(it), local.view(it)))
+    stats = torch.tensor([elapsed, t_comp or 0.0, t_decomp or 0.0, float(body_len), float(ok)], dtype=torch.float64, device=device)
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -293,7 +444,9 @@ def main():
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         mn = stats.clone()
         dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-        elapsed, t_comp, t_decomp = float(mx[0]), float(mx[1]), float(mx[2])
+        elapsed = float(mx[0])
+        t_comp = float(mx[1]) if t_comp is not None else None
+        t_decomp = float(mx[2]) if t_decomp is not None else None
         total_body_words = float(sm[3])
         ok = bool(mn[4] > 0.5)
     else:
@@ -302,14 +455,27 @@ def main():
     if rank == 0:
         wb = np_dtype.itemsize
         nhc_total = ndzip_amd.num_hypercubes(global_extent)
-        raw_total = raw_bytes_local * world
+        raw_total = float(np.prod(global_extent, dtype=np.float64)) * wb
         stream_bytes_total = (ndzip_amd.header_words(np_dtype, nhc_total) + total_body_words) * wb
         ratio = stream_bytes_total / raw_total
-        value = 2 * raw_total * args.steps / elapsed / 1e9
-        comp_gbps = raw_total / t_comp / 1e9
-        decomp_gbps = raw_total / t_decomp / 1e9
-        algo_bytes_per_launch = raw_bytes_local + stream_bytes_total / world   # per GPU: N read + C written
-        achieved = algo_bytes_per_launch / t_comp / 1e9
+        passes = 2 if mode == "both" else 1
+        value = passes * raw_total * args.steps / elapsed / 1e9
+        # per GPU and launch: N read + C written (compress), C read + N written (decompress) -- SURVEY 8d
+        algo_bytes_per_launch = (raw_total + stream_bytes_total) / world
+        slabs = plan_shards(global_extent, world)
+        kernel_c = f"compress_kernel_db<float,{dims}>" if wb == 4 else f"compress_kernel_wide<unsigned long,{dims}>"
+        kernel_d = f"decompress_kernel<{'float' if wb == 4 else 'double'},{dims}>"
+
+        def leg(t):
+            a = algo_bytes_per_launch / t / 1e9
+            return {"achieved": round(a, 2), "frac": round(a / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(a / HBM_COPY_GBPS, 4),
+                    "launch_ms": round(t * 1e3, 4), "uncompressed_GBps": round(raw_total / world / t / 1e9, 2)}
+
+        dominant_t, dominant_k = (t_decomp, kernel_d) if mode == "decompress" else (t_comp, kernel_c)
+        roofline = {"bound": "hbm", "kernel": dominant_k, **leg(dominant_t), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
+                    "algorithmic_bytes_per_launch": int(algo_bytes_per_launch)}
+        if mode == "both":
+            roofline["decompress"] = {"kernel": kernel_d, **leg(t_decomp)}
         result = {
             "metric": "compress + decompress GB/s (uncompressed) per GPU; % of HBM3E peak",
             "value": round(value, 2),
@@ -319,58 +485,52 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32" if wb == 4 else "u64",
             "data": "synthetic" if args.data == "synthetic" else args.data,
             "config": {
-                "workload": f"{dims}D {np_dtype.name} {'x'.join(map(str, global_extent))} synthetic turbulence "
+                "workload": f"{desc}: {dims}D {np_dtype.name} {'x'.join(map(str, global_extent))} synthetic turbulence "
                             f"(Appendix-B generator seed 1, noise_mask {args.noise_mask:#x}{', smooth' if args.smooth else ''}); "
-                            f"{world} z-slab(s) of {'x'.join(map(str, per_gpu))}",
+                            f"{world} z-slab(s) of {'x'.join(map(str, slabs[0].extent))}",
+                "baseline_config": args.config if not args.shape else None,
                 "hypercubes": nhc_total,
                 "compression_ratio": round(ratio, 4),
-                "step": "compress then decompress, inputs resident in HBM",
+                "step": {"both": "compress then decompress", "compress": "compress only", "decompress": "decompress only"}[mode]
+                        + ", inputs resident in HBM",
                 "parallelism": f"hypercube-range sharding x{world}" + (" (RCCL all-gather of offsets + header)" if world > 1 else ""),
             },
-            "per_gpu": {
-                "compress_GBps": round(comp_gbps / world, 2),
-                "decompress_GBps": round(decomp_gbps / world, 2),
-                "compress_frac_of_hbm_peak": round(comp_gbps / world / HBM_PEAK_GBPS, 4),
-                "decompress_frac_of_hbm_peak": round(decomp_gbps / world / HBM_PEAK_GBPS, 4),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": f"compress_kernel_db<float,{dims}>" if wb == 4 else f"compress_kernel_wide<unsigned long,{dims}>",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
-                "traffic": None,
-                "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
-                "launch_ms": round(t_comp * 1e3, 4),
-                "decompress": {
-                    "achieved": round(algo_bytes_per_launch / t_decomp / 1e9, 2),
-                    "frac": round(algo_bytes_per_launch / t_decomp / 1e9 / HBM_PEAK_GBPS, 4),
-                    "launch_ms": round(t_decomp * 1e3, 4),
-                },
-            },
+            "per_gpu": {},
+            "roofline": roofline,
             "roundtrip_bit_exact": ok,
         }
+        if args.lib:
+            result["config"]["lib"] = args.lib
+        if t_comp is not None:
+            result["per_gpu"]["compress_GBps"] = round(raw_total / world / t_comp / 1e9, 2)
+            result["per_gpu"]["compress_frac_of_hbm_peak"] = round(raw_total / world / t_comp / 1e9 / HBM_PEAK_GBPS, 4)
+        if t_decomp is not None:
+            result["per_gpu"]["decompress_GBps"] = round(raw_total / world / t_decomp / 1e9, 2)
+            result["per_gpu"]["decompress_frac_of_hbm_peak"] = round(raw_total / world / t_decomp / 1e9 / HBM_PEAK_GBPS, 4)
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             try:
                 with open(traffic_file) as f:
                     tr = json.load(f)
-                key = f"{np_dtype.name}-{'x'.join(map(str, per_gpu))}"
+                key = f"{np_dtype.name}-{'x'.join(map(str, slabs[0].extent))}"
                 if key in tr:
-                    result["roofline"]["traffic"] = tr[key]["compress_hbm_bytes_per_launch"]
+                    which = "decompress_hbm_bytes_per_launch" if mode == "decompress" else "compress_hbm_bytes_per_launch"
+                    result["roofline"]["traffic"] = tr[key].get(which)
                     result["roofline"]["traffic_source"] = tr[key].get("source")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
+            # a bounded sample of the same workload: at most 512 MiB of leading rows of dimension 0 (whole hypercube planes)
+            side = {1: 4096, 2: 64, 3: 16}[dims]
+            row_bytes = raw_bytes_local // max(1, local.shape[0])
+            rows = min(local.shape[0], max(side, (512 << 20) // max(1, row_bytes) // side * side))
             try:
-                result.update(cpu_baseline(local.cpu().numpy(), dims))
+                result.update(cpu_legs(local[:rows].cpu().numpy(), args.cpu_budget))
             except Exception as e:  # the checker is optional for the GPU number, never the other way round
                 result["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(result), flush=True)
@@ -384,20 +544,14 @@ def synth_slab(synth_torch, global_extent, shard, t_dtype, device, noise_mask, s
     """Generate this rank's z-slab of the global field (values depend on global coordinates and linear index)."""
     import torch
 
-    if shard.start0 == 0 and shard.extent == tuple(global_extent):
-        return synth_torch(global_extent, t_dtype, seed=1, noise_mask=noise_mask, smooth=smooth, device=device)
-    # generate plane blocks of the global grid and keep only this slab
-    planes = shard.extent[0]
-    rest = tuple(global_extent[1:])
-    out = torch.empty(shard.extent, dtype=t_dtype, device=device)
     from ndzip_amd.synth import synth_torch_range
 
-    per_plane = 1
-    for x in rest:
-        per_plane *= x
-    flat = out.view(-1)
-    synth_torch_range(global_extent, t_dtype, shard.start0 * per_plane, planes * per_plane, flat, seed=1,
-                      noise_mask=noise_mask, smooth=smooth)
+    rest = 1
+    for x in global_extent[1:]:
+        rest *= x
+    out = torch.empty(shard.extent, dtype=t_dtype, device=device)
+    synth_torch_range(global_extent, t_dtype, shard.start0 * rest, shard.extent[0] * rest, out.view(-1), seed=1, noise_mask=noise_mask,
+                      smooth=smooth)
     return out
 
 

@@ -18,7 +18,6 @@ device tensors) on the GPU box and over gloo (CPU tensors) in the world_size-2 C
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -110,7 +109,7 @@ class ShardedCodec:
     lengths, added to the local header entries) -> all-gather of the header segments.  The steps are public so that a test
     can play every rank of a plan on one GPU."""
 
-    def __init__(self, dtype, global_extent: Sequence[int], rank: int, world: int, device, group=None):
+    def __init__(self, dtype, global_extent: Sequence[int], rank: int, world: int, device, group=None, async_header_gather: bool = False):
         import numpy as np
         import torch
 
@@ -120,6 +119,9 @@ class ShardedCodec:
         self.extent = tuple(int(x) for x in global_extent)
         self.dims = len(self.extent)
         self.rank, self.world, self.group = rank, world, group
+        # True leaves the header all-gather in flight behind decompress (off until it has run on a multi-GPU node; the
+        # default issues it synchronously on the process group's stream)
+        self.async_header_gather = async_header_gather
         self.device = device
         self.shards = plan_shards(self.extent, world)
         self.shard = self.shards[rank]
@@ -188,9 +190,7 @@ class ShardedCodec:
         dist.all_gather_into_tensor(self.lens_all, self.body_len, group=self.group)   # world x 4 bytes
         self.globalise()
         m = max(self.sizes)
-        # NDZIP_SHARDED_ASYNC_GATHER=1 leaves the header all-gather in flight behind decompress (opt-in until it has run on a
-        # multi-GPU node; the default issues it synchronously on the process group's stream)
-        if m > 0 and all(n == m for n in self.sizes) and os.environ.get("NDZIP_SHARDED_ASYNC_GATHER") == "1":
+        if m > 0 and all(n == m for n in self.sizes) and self.async_header_gather:
             if self._header_global is None or self._header_global.numel() != self.world * m:
                 self._header_global = torch.empty(self.world * m, dtype=torch.int32, device=self.device)
             self._pending = dist.all_gather_into_tensor(self._header_global, self.header_local[:m], group=self.group, async_op=True)
