@@ -62,7 +62,12 @@ NDZIP_DEV uint32_t desc_state(tile_desc d, uint32_t epoch) {
 #define NDZIP_LOOKBACK_LANES 64
 #endif
 constexpr int lookback_lanes = NDZIP_LOOKBACK_LANES;
-constexpr uint32_t spin_limit = 1u << 20;
+// polls (with s_sleep between them, ~0.2 s in all) after which a look-back gives up and sets the error word; overridable only
+// so that the parity tests can force the give-up path
+#ifndef NDZIP_LOOKBACK_SPIN_LIMIT
+#define NDZIP_LOOKBACK_SPIN_LIMIT (1u << 20)
+#endif
+constexpr uint32_t spin_limit = NDZIP_LOOKBACK_SPIN_LIMIT;
 
 NDZIP_DEV tile_desc desc_load(const tile_desc *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -227,15 +232,15 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
             }
             spins = __shfl(spins, 0, 64);
             if (spins >= spin_limit) {
-                timed_out = true;
-                found = false;
+                timed_out = true;  // (`found` / `lf` stay: an inclusive prefix in the window still bounds what may be summed)
                 break;
             }
         }
         // After a timeout some lanes still hold UNPUBLISHED descriptors, whose value field is whatever an earlier launch
-        // left there (the scratch is never cleared: epoch tags): those lanes contribute 0, so the prefix returned on a
-        // timeout is a partial sum of real lengths -- never larger than the true prefix, which keeps every write of
-        // this tile inside the caller's buffer.
+        // left there (the scratch is never cleared: epoch tags): those lanes contribute 0.  Lanes beyond the nearest
+        // inclusive prefix stay excluded as always (their lengths are part of that prefix).  So the prefix returned on a
+        // timeout is a partial sum of real lengths -- never larger than the true prefix, which keeps every write of this
+        // tile inside the caller's buffer.
         const bool take = (!found || lane <= lf) && desc_state(d, desc.epoch) != 0;
         exclusive += wave_sum(take ? static_cast<uint32_t>(d) : 0u);
         if (found || timed_out) break;

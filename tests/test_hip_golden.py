@@ -36,8 +36,11 @@ def test_hip_reproduces_reference_stream_hashes(hiplib, cuda_device, case):
     assert same_bits(device_decompress(stream, data.dtype, data.shape), data)
 
 
+# every BASELINE.json config at full size; configs 4 and 5 as the z-slab one of the 8 ranks owns (the sharded path itself is
+# tests/test_hip_sharded.py and the gloo test): 65 536 resp. 32 768 hypercubes, 1 GiB each
 FULL = [("cfg2 3D f32 512^3", (512, 512, 512), np.float32), ("cfg3 2D f64 8192^2", (8192, 8192), np.float64),
-        ("cfg1 1D f32 16Mi", (1 << 24,), np.float32)]
+        ("cfg1 1D f32 16Mi", (1 << 24,), np.float32), ("cfg4 rank slab 3D f32 256x1024x1024", (256, 1024, 1024), np.float32),
+        ("cfg5 rank slab 3D f64 128x1024x1024", (128, 1024, 1024), np.float64)]
 
 
 @pytest.mark.parametrize("name,shape,dtype", FULL, ids=[f[0] for f in FULL])

@@ -194,3 +194,42 @@ def test_host_pointer_offloader_and_pipelined_offloader(profile):
         words, _ = po.wait(0)
         assert words == len(want) and same_bits(back2, data)
         po.close()
+
+
+def test_lookback_timeout_stays_in_bounds_and_is_reported():
+    """A look-back that gives up (library variant with a spin limit of 0: any wait for a predecessor is a timeout) after a
+    LARGER earlier launch on the same handle, whose descriptors are still in the scratch with another epoch: the partial
+    prefix must consist of published lengths only (no write past the stream bound, no wild address), the error word must be
+    set (check() fails) and the stream length must be poisoned to 0 for callers that never check."""
+    sim.load("spin0", defines=("NDZIP_LOOKBACK_SPIN_LIMIT=0",))
+    big = synth_numpy((16 * 6, 16 * 4, 16 * 4), np.float32, seed=1, noise_mask=0xFFFF)
+    small = synth_numpy((16 * 2, 16 * 4, 16 * 4), np.float32, seed=2, noise_mask=0xFFFF)
+    want = oracle.compress(small)
+    saw_timeout = False
+    with sim.active(cus=4, blocks_per_cu=3, variant="spin0"):
+        comp = hip.make_hip_compressor(np.float32, hip.CompressorRequirements(big.shape))
+        bound_big = hip.compressed_length_bound(np.float32, big.shape)
+        bound = hip.compressed_length_bound(np.float32, small.shape)
+        for attempt in range(20):
+            out_big = np.zeros(bound_big, dtype=np.uint32)
+            length = np.zeros(1, dtype=np.uint32)
+            comp.compress(big.ctypes.data, big.shape, out_big.ctypes.data, length.ctypes.data)
+            try:
+                comp.check()
+            except hip.NdzipHipError:
+                pass
+            canary = 0xDEADBEEF
+            out = np.full(bound + 4096, canary, dtype=np.uint32)
+            length[0] = 12345
+            comp.compress(small.ctypes.data, small.shape, out.ctypes.data, length.ctypes.data)
+            assert (out[bound:] == canary).all(), "a write went past the caller's stream buffer"
+            try:
+                comp.check()
+                assert int(length[0]) == len(want) and np.array_equal(out[: len(want)], want)  # no timeout: a correct stream
+            except hip.NdzipHipError as e:
+                assert "look-back timeout" in str(e)
+                assert int(length[0]) == 0, "a timed-out launch must poison the stream length"
+                saw_timeout = True
+                break
+        comp.close()
+    assert saw_timeout, "the spin-limit-0 variant never had to wait for a predecessor in 20 attempts"

@@ -30,7 +30,11 @@ def _sources():
     return files
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> str:
+    """variant / defines: a second library built with extra -D flags (e.g. a tiny look-back spin limit), suffixed _<variant>."""
+    OUT = os.path.join(HERE, f"libndzip_hip_wavesim{'_' + variant if variant else ''}.so")
+    BUILD = os.path.join(HERE, "_build", variant or "default")
+    FLAGS = list(globals()["FLAGS"]) + [f"-D{d}" for d in defines]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in _sources()):
         return OUT
     # mirror the product tree so that its relative includes resolve, with the one substituted header

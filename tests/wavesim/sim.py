@@ -12,20 +12,19 @@ from ndzip_amd import hip
 
 from . import build as simbuild
 
-_sim = None
+_sim = {}
 
 
-def load():
-    global _sim
-    if _sim is None:
-        _sim = hip._bind(C.CDLL(simbuild.build()))
-    return _sim
+def load(variant: str = "", defines=()):
+    if variant not in _sim:
+        _sim[variant] = hip._bind(C.CDLL(simbuild.build(variant=variant, defines=defines)))
+    return _sim[variant]
 
 
 @contextlib.contextmanager
-def active(cus: int = 2, blocks_per_cu: int = 2):
+def active(cus: int = 2, blocks_per_cu: int = 2, variant: str = ""):
     """Route ndzip_amd.hip's ctypes calls to the model for the duration of the block (tests only: the product never does)."""
-    L = load()
+    L = load(variant)
     saved, env = hip._lib, {k: os.environ.get(k) for k in ("WAVESIM_CUS", "WAVESIM_BLOCKS_PER_CU")}
     os.environ["WAVESIM_CUS"] = str(cus)
     os.environ["WAVESIM_BLOCKS_PER_CU"] = str(blocks_per_cu)
