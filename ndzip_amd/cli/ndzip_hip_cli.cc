@@ -12,6 +12,16 @@
 //     j-1 overlap) through ndzip_hip_offloader_*; the reference's loop is one blocking offloader call per chunk.
 //   * the summary line reports the true raw size (the reference multiplies by the chunk count twice, compress.cc:50-51).
 //   * a trailing partial array is an error for compression, as in the reference (io.cc read_exact).
+//
+// I/O follows src/io/io.cc: regular files are memory-mapped unless `--no-mmap` is given (mmap_input_stream /
+// mmap_output_stream, io.cc:118-256: the input is mapped once and handed to the device copy in place; the output file grows by
+// one mapped window per array and is truncated to its final length), stdin / stdout and `--no-mmap` go through stdio
+// (stdio_input_stream / stdio_output_stream, io.cc:17-116) and pinned buffers.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cerrno>
 #include <chrono>
 #include <cinttypes>
@@ -36,6 +46,7 @@ struct options {
     std::string output = "-";
     int slots = 3;
     bool quiet = false;
+    bool use_mmap = true;  // compress.cc:150,211-216: memory-mapped I/O unless --no-mmap
 };
 
 [[noreturn]] void usage_error(const std::string &msg, const char *argv0) {
@@ -51,7 +62,7 @@ struct options {
             "  -i [ --input ] arg        input file (default '-' is stdin)\n"
             "  -o [ --output ] arg       output file (default '-' is stdout)\n"
             "  --slots arg               arrays in flight on the device (default 3)\n"
-            "  --no-mmap                 accepted, ignored (I/O is buffered through pinned memory)\n"
+            "  --no-mmap                 do not use memory-mapped I/O (stdin / stdout never are)\n"
             "  -q [ --quiet ]            no summary line\n");
     exit(EXIT_FAILURE);
 }
@@ -103,6 +114,7 @@ options parse(int argc, char **argv) {
         } else if (a == "--slots") {
             o.slots = static_cast<int>(parse_u32(value("--slots"), argv[0]));
         } else if (a == "--no-mmap") {
+            o.use_mmap = false;
         } else if (a == "-q" || a == "--quiet") {
             o.quiet = true;
         } else {
@@ -115,33 +127,170 @@ options parse(int argc, char **argv) {
     return o;
 }
 
-struct file {
-    FILE *f = nullptr;
+bool is_path(const std::string &name) { return !name.empty() && name != "-"; }
+
+// ---- input: a run of bytes consumed front to back; `take` returns a pointer to the next `bytes` bytes (valid until the job
+// that uses them has been retired), which is either inside the mapping or the caller's own buffer filled by fread ------------
+struct input {
+    virtual ~input() = default;
+    // up to `bytes` bytes: *got = how many there were (0 at the end of the input)
+    virtual const void *take(size_t bytes, void *own_buffer, size_t *got) = 0;
+    // mapped input only: everything that is left, without consuming it
+    virtual bool is_mapped() const { return false; }
+    virtual const void *peek(size_t *available) {
+        *available = 0;
+        return nullptr;
+    }
+};
+
+struct stdio_input final : input {  // io.cc:17-66
+    FILE *f = stdin;
     bool owned = false;
-    file(const std::string &name, bool write) {
-        if (!name.empty() && name != "-") {
-            f = fopen(name.c_str(), write ? "wb" : "rb");
+    explicit stdio_input(const std::string &name) {
+        if (is_path(name)) {
+            f = fopen(name.c_str(), "rb");
             if (!f) throw std::runtime_error("fopen: " + name + ": " + strerror(errno));
             owned = true;
-        } else {
-            f = write ? stdout : stdin;
         }
     }
-    ~file() {
-        if (owned && f) fclose(f);
+    ~stdio_input() override {
+        if (owned) fclose(f);
     }
-    size_t read(void *dst, size_t bytes) {
-        const size_t n = fread(dst, 1, bytes, f);
-        if (n < bytes && ferror(f)) throw std::runtime_error(std::string("fread: ") + strerror(errno));
-        return n;
+    const void *take(size_t bytes, void *own_buffer, size_t *got) override {
+        *got = fread(own_buffer, 1, bytes, f);
+        if (*got < bytes && ferror(f)) throw std::runtime_error(std::string("fread: ") + strerror(errno));
+        return own_buffer;
     }
-    void write(const void *src, size_t bytes) {
-        if (bytes && fwrite(src, bytes, 1, f) < 1) throw std::runtime_error(std::string("fwrite: ") + strerror(errno));
+};
+
+struct mapped_input final : input {  // io.cc:118-176
+    int fd = -1;
+    void *map = nullptr;
+    size_t size = 0, offset = 0;
+    explicit mapped_input(const std::string &name) {
+        fd = open(name.c_str(), O_RDONLY);
+        if (fd == -1) throw std::runtime_error("open: " + name + ": " + strerror(errno));
+        struct stat st {};
+        if (fstat(fd, &st) == -1) {
+            close(fd);
+            throw std::runtime_error("fstat: " + name + ": " + strerror(errno));
+        }
+        size = static_cast<size_t>(st.st_size);
+        if (size) {
+            map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (map == MAP_FAILED) {
+                close(fd);
+                throw std::runtime_error("mmap: " + name + ": " + strerror(errno));
+            }
+        }
     }
-    void flush() {
+    ~mapped_input() override {
+        if (map) munmap(map, size);
+        close(fd);
+    }
+    const void *take(size_t bytes, void *, size_t *got) override {
+        const char *p = static_cast<const char *>(map) + offset;
+        *got = bytes < size - offset ? bytes : size - offset;
+        offset += *got;
+        return p;
+    }
+    bool is_mapped() const override { return true; }
+    const void *peek(size_t *available) override {
+        *available = size - offset;
+        return static_cast<const char *>(map) + offset;
+    }
+};
+
+// ---- output: arrays are committed in order; `window` is where the next `max_bytes` bytes may be produced in place (nullptr:
+// produce them in your own buffer and pass it to commit) ----------------------------------------------------------------------
+struct output {
+    virtual ~output() noexcept(false) {}
+    virtual void *window(size_t max_bytes) = 0;
+    virtual void commit(const void *data, size_t bytes) = 0;  // `data`: the window handed out for this array, or an own buffer
+    virtual void finish() = 0;
+};
+
+struct stdio_output final : output {  // io.cc:69-116
+    FILE *f = stdout;
+    bool owned = false;
+    explicit stdio_output(const std::string &name) {
+        if (is_path(name)) {
+            f = fopen(name.c_str(), "wb");
+            if (!f) throw std::runtime_error("fopen: " + name + ": " + strerror(errno));
+            owned = true;
+        }
+    }
+    ~stdio_output() noexcept(false) override {
+        if (owned) fclose(f);
+    }
+    void *window(size_t) override { return nullptr; }
+    void commit(const void *data, size_t bytes) override {
+        if (bytes && fwrite(data, bytes, 1, f) < 1) throw std::runtime_error(std::string("fwrite: ") + strerror(errno));
+    }
+    void finish() override {
         if (fflush(f) != 0) throw std::runtime_error(std::string("fflush: ") + strerror(errno));
     }
 };
+
+// The file grows by one mapped window per array (ftruncate + mmap of the page-aligned range that holds it) and is truncated to
+// the committed length at the end -- mmap_output_stream (io.cc:178-256) with several windows alive at a time, because several
+// arrays are in flight.  Windows are handed out at a provisional offset = committed bytes + the maximum sizes of the arrays in
+// flight before this one; an array that turns out shorter than its maximum (compression) makes the later in-flight windows sit
+// too far back, so commit() moves such an array forward to its final place (one memmove inside the page cache).
+struct mapped_output final : output {
+    struct win {
+        void *base;      // mmap result
+        size_t map_len;  // length of the mapping
+        char *data;      // where the array was produced
+        size_t offset;   // provisional file offset of `data`
+    };
+    int fd = -1;
+    size_t committed = 0, reserved = 0, page;
+    std::vector<win> live;  // in hand-out order
+    explicit mapped_output(const std::string &name) : page(static_cast<size_t>(sysconf(_SC_PAGESIZE))) {
+        fd = open(name.c_str(), O_RDWR | O_TRUNC | O_CREAT, static_cast<mode_t>(0666));
+        if (fd == -1) throw std::runtime_error("open: " + name + ": " + strerror(errno));
+    }
+    ~mapped_output() noexcept(false) override {
+        for (auto &w : live) munmap(w.base, w.map_len);
+        close(fd);
+    }
+    void *window(size_t max_bytes) override {
+        const size_t offset = reserved;
+        reserved += max_bytes;
+        if (ftruncate(fd, static_cast<off_t>(reserved)) == -1) throw std::runtime_error(std::string("ftruncate: ") + strerror(errno));
+        const size_t aligned = offset / page * page, len = offset - aligned + (max_bytes ? max_bytes : 1);
+        void *base = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, static_cast<off_t>(aligned));
+        if (base == MAP_FAILED) throw std::runtime_error(std::string("mmap: ") + strerror(errno));
+        live.push_back({base, len, static_cast<char *>(base) + (offset - aligned), offset});
+        return live.back().data;
+    }
+    void commit(const void *data, size_t bytes) override {
+        if (live.empty() || live.front().data != data) throw std::runtime_error("output windows are committed in hand-out order");
+        win w = live.front();
+        live.erase(live.begin());
+        if (w.offset != committed && bytes) {  // an earlier array was shorter than its window: move this one up to its place
+            if (pwrite(fd, w.data, bytes, static_cast<off_t>(committed)) != static_cast<ssize_t>(bytes)) {
+                throw std::runtime_error(std::string("pwrite: ") + strerror(errno));
+            }
+        }
+        if (munmap(w.base, w.map_len) == -1) throw std::runtime_error(std::string("munmap: ") + strerror(errno));
+        committed += bytes;
+    }
+    void finish() override {
+        if (ftruncate(fd, static_cast<off_t>(committed)) == -1) throw std::runtime_error(std::string("ftruncate: ") + strerror(errno));
+    }
+};
+
+std::unique_ptr<input> open_input(const options &o) {
+    if (o.use_mmap && is_path(o.input)) return std::make_unique<mapped_input>(o.input);
+    return std::make_unique<stdio_input>(o.input);
+}
+
+std::unique_ptr<output> open_output(const options &o) {
+    if (o.use_mmap && is_path(o.output)) return std::make_unique<mapped_output>(o.output);
+    return std::make_unique<stdio_output>(o.output);
+}
 
 struct pinned {
     void *p = nullptr;
@@ -204,9 +353,11 @@ sizes sizes_of(const options &o) {
 // compress.cc:17-58
 void compress_file(const options &o) {
     const sizes z = sizes_of(o);
-    file in(o.input, false), out(o.output, true);
+    auto in = open_input(o);
+    auto out = open_output(o);
     offloader off(o.dtype, z.dims, o.size.data(), o.slots);
     job_buffers buf(o.slots, z.chunk_bytes, z.bound_bytes);
+    std::vector<void *> dest(o.slots, nullptr);  // where each slot's stream is produced: an output window or the pinned buffer
     pipeline pipe(o.slots);
     size_t compressed_words = 0;
     uint64_t kernel_ns = 0;
@@ -216,7 +367,7 @@ void compress_file(const options &o) {
         uint32_t words = 0;
         uint64_t ns = 0;
         check(ndzip_hip_offloader_wait(off.h, slot, &words, &ns), "compress");
-        out.write(buf.out[slot]->p, static_cast<size_t>(words) * z.wb);
+        out->commit(dest[slot], static_cast<size_t>(words) * z.wb);
         compressed_words += words;
         kernel_ns += ns;
         ++pipe.retired;
@@ -224,14 +375,17 @@ void compress_file(const options &o) {
     for (;;) {
         if (pipe.full()) retire();
         const int slot = pipe.next_slot();
-        const size_t got = in.read(buf.in[slot]->p, z.chunk_bytes);
+        size_t got = 0;
+        const void *chunk = in->take(z.chunk_bytes, buf.in[slot]->p, &got);
         if (got == 0) break;
         if (got != z.chunk_bytes) throw std::runtime_error("Input file size is not a multiple of the chunk size");  // io.cc read_exact
-        check(ndzip_hip_offloader_submit_compress(off.h, slot, o.size.data(), buf.in[slot]->p, buf.out[slot]->p), "compress");
+        void *w = out->window(z.bound_bytes);
+        dest[slot] = w ? w : buf.out[slot]->p;
+        check(ndzip_hip_offloader_submit_compress(off.h, slot, o.size.data(), chunk, dest[slot]), "compress");
         ++pipe.submitted;
     }
     while (!pipe.empty()) retire();
-    out.flush();
+    out->finish();
     if (!o.quiet) {
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const size_t n_chunks = pipe.submitted, raw = n_chunks * z.chunk_bytes, comp = compressed_words * z.wb;
@@ -245,35 +399,54 @@ void compress_file(const options &o) {
 // compress.cc:61-86
 void decompress_file(const options &o) {
     const sizes z = sizes_of(o);
-    file in(o.input, false), out(o.output, true);
+    auto in = open_input(o);
+    auto out = open_output(o);
     offloader off(o.dtype, z.dims, o.size.data(), o.slots);
     job_buffers buf(o.slots, z.bound_bytes, z.chunk_bytes);
+    std::vector<void *> dest(o.slots, nullptr);
     pipeline pipe(o.slots);
     auto retire = [&] {
         const int slot = pipe.oldest_slot();
         check(ndzip_hip_offloader_wait(off.h, slot, nullptr, nullptr), "decompress");
-        out.write(buf.out[slot]->p, z.chunk_bytes);
+        out->commit(dest[slot], z.chunk_bytes);
         ++pipe.retired;
     };
     for (;;) {
         if (pipe.full()) retire();
         const int slot = pipe.next_slot();
-        // one stream = header (whose last entry gives the body length) + bodies + border: read the header, then the rest
-        char *stream = static_cast<char *>(buf.in[slot]->p);
-        const size_t got = in.read(stream, z.header_bytes);
-        if (got == 0 && z.header_bytes > 0) break;
-        if (got != z.header_bytes) throw std::runtime_error("truncated stream header in input");
+        // one stream = header (whose last entry gives the body length) + bodies + border
+        const void *stream = nullptr;
         uint32_t words = 0;
-        check(ndzip_hip_stream_words(o.dtype, z.dims, o.size.data(), stream, z.bound_words, &words), "stream header");
-        const size_t rest = static_cast<size_t>(words) * z.wb - z.header_bytes;
-        const size_t got_rest = in.read(stream + z.header_bytes, rest);
-        if (z.header_bytes == 0 && got_rest == 0) break;  // array without hypercubes: the stream is the border alone
-        if (got_rest != rest) throw std::runtime_error("truncated stream in input");
-        check(ndzip_hip_offloader_submit_decompress(off.h, slot, o.size.data(), stream, words, buf.out[slot]->p), "decompress");
+        size_t available = 0;
+        if (in->is_mapped()) {
+            // mapped input: the stream is sized, validated and used in place
+            const void *mapped = in->peek(&available);
+            if (available == 0) break;
+            check(ndzip_hip_stream_words(o.dtype, z.dims, o.size.data(), mapped, available / z.wb, &words), "stream header");
+            size_t got = 0;
+            stream = in->take(static_cast<size_t>(words) * z.wb, nullptr, &got);
+        } else {
+            // stdio: read the header, then the rest
+            char *dst = static_cast<char *>(buf.in[slot]->p);
+            size_t got = 0;
+            in->take(z.header_bytes, dst, &got);
+            if (got == 0 && z.header_bytes > 0) break;
+            if (got != z.header_bytes) throw std::runtime_error("truncated stream header in input");
+            check(ndzip_hip_stream_words(o.dtype, z.dims, o.size.data(), dst, z.bound_words, &words), "stream header");
+            const size_t rest = static_cast<size_t>(words) * z.wb - z.header_bytes;
+            size_t got_rest = 0;
+            in->take(rest, dst + z.header_bytes, &got_rest);
+            if (z.header_bytes == 0 && got_rest == 0) break;  // array without hypercubes: the stream is the border alone
+            if (got_rest != rest) throw std::runtime_error("truncated stream in input");
+            stream = dst;
+        }
+        void *w = out->window(z.chunk_bytes);
+        dest[slot] = w ? w : buf.out[slot]->p;
+        check(ndzip_hip_offloader_submit_decompress(off.h, slot, o.size.data(), stream, words, dest[slot]), "decompress");
         ++pipe.submitted;
     }
     while (!pipe.empty()) retire();
-    out.flush();
+    out->finish();
 }
 
 }  // namespace

@@ -88,3 +88,67 @@ def test_benchmark_tool_parses_the_reference_dataset_csv(tmp_path):
     assert r.stdout.decode().strip() == ("dataset;data type;dimensions;algorithm;tunable;number of threads;"
                                          "compression times (microseconds);decompression times (microseconds);"
                                          "uncompressed bytes;compressed bytes")
+
+
+@pytest.fixture(scope="module")
+def model_cli(tmp_path_factory):
+    """The file tool linked against the wave64 functional model of the library (tests/wavesim, test infrastructure): the whole
+    tool -- option parsing, mapped and buffered I/O, the pipelined chunk loop, the C ABI and the kernels' logic -- on the CPU."""
+    from tests.wavesim import build as simbuild
+
+    lib = simbuild.build()
+    exe = str(tmp_path_factory.mktemp("cli") / "ndzip-hip-model")
+    src = os.path.join(os.path.dirname(build.__file__), "cli", "ndzip_hip_cli.cc")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, src, lib, "-Wl,-rpath," + os.path.dirname(lib)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.parametrize("io", ["mmap", "no-mmap", "pipes"])
+@pytest.mark.parametrize("dtype,shape,chunks", [(np.float32, (32, 32, 48), 4), (np.float64, (70, 130), 3), (np.float32, (4096 * 2 + 9,), 5)])
+def test_file_roundtrip_matches_the_reference_format(model_cli, tmp_path, io, dtype, shape, chunks):
+    """compress.cc:17-86: the output is the plain concatenation of one stream per array; files are interchangeable with the
+    reference tool's (= the oracle's streams); mapped and buffered I/O (src/io/io.cc) give identical files."""
+    from ndzip_amd.synth import synth_numpy
+
+    arrays = [synth_numpy(shape, dtype, seed=10 + i, noise_mask=0xFF if i % 2 else 0xFFFFF) for i in range(chunks)]
+    arrays[1][...] = 0  # a highly compressible array next to poorly compressible ones: in-flight output windows must move up
+    raw = np.concatenate([a.reshape(-1) for a in arrays])
+    want = np.concatenate([oracle.compress(a) for a in arrays])
+    src, ndz, back = tmp_path / "in.bin", tmp_path / "out.ndz", tmp_path / "back.bin"
+    raw.tofile(src)
+    size = [str(x) for x in shape]
+    t = ["-t", "double"] if dtype == np.float64 else []
+    if io == "pipes":
+        r = run(model_cli, "-n", *size, *t, stdin=raw.tobytes())
+        assert r.returncode == 0, r.stderr
+        got = np.frombuffer(r.stdout, dtype=want.dtype)
+        r2 = run(model_cli, "-d", "-n", *size, *t, stdin=r.stdout)
+        assert r2.returncode == 0, r2.stderr
+        out = np.frombuffer(r2.stdout, dtype=dtype)
+    else:
+        extra = ["--no-mmap"] if io == "no-mmap" else []
+        r = run(model_cli, "-n", *size, *t, "-i", str(src), "-o", str(ndz), *extra)
+        assert r.returncode == 0, r.stderr
+        assert b"ratio" in r.stderr and f"({chunks} chunks".encode() in r.stderr
+        got = np.fromfile(ndz, dtype=want.dtype)
+        r2 = run(model_cli, "-d", "-n", *size, *t, "-i", str(ndz), "-o", str(back), *extra)
+        assert r2.returncode == 0, r2.stderr
+        out = np.fromfile(back, dtype=dtype)
+    assert len(got) == len(want) and np.array_equal(got, want)
+    assert np.array_equal(out.view(want.dtype), raw.view(want.dtype))
+
+
+def test_file_tool_rejects_partial_and_corrupt_input(model_cli, tmp_path):
+    src = tmp_path / "in.bin"
+    np.zeros(4096 + 5, dtype=np.float32).tofile(src)
+    r = run(model_cli, "-n", "4096", "-i", str(src), "-o", str(tmp_path / "o.ndz"))
+    assert r.returncode != 0 and b"not a multiple of the chunk size" in r.stderr
+    good = oracle.compress(np.ones(4096 * 2, dtype=np.float32))
+    bad = good.copy()
+    bad[0] = 0xFFFFFF00  # first header entry
+    for blob, msg in ((bad, b"corrupt stream header"), (good[:-3], b"longer than the given words")):
+        f = tmp_path / "bad.ndz"
+        blob.tofile(f)
+        r = run(model_cli, "-d", "-n", "8192", "-i", str(f), "-o", str(tmp_path / "b.bin"))
+        assert r.returncode != 0 and msg in r.stderr, r.stderr
