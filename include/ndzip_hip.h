@@ -200,6 +200,29 @@ NDZIP_HIP_API int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uin
 NDZIP_HIP_API int ndzip_hip_stream_words(int dtype, int dims, const uint32_t *extent, const void *stream, uint64_t available_words,
         uint32_t *words);
 
+/* ---- arrays beyond the format's 32-bit counts ------------------------------------------------------------------------------
+ * index_type is uint32_t (include/ndzip/ndzip.hh:20): one ndzip stream holds fewer than 2^32 elements and fewer than 2^32
+ * words.  The reference handles larger data at the file level only -- its tool cuts the input into arrays of `-n` elements and
+ * concatenates one stream per array (src/compress/compress.cc:34-45).  These entry points do the same for ONE large host
+ * array: dimension 0 (given in 64 bits) is cut into the fewest slabs of whole hypercube rows that are legal ndzip arrays,
+ * slab k covers rows [k * rows_per_chunk, min((k + 1) * rows_per_chunk, extent[0])), every slab becomes an independent
+ * stream -- bit-identical to what the reference produces for that slab as an array of its own -- and the streams are
+ * concatenated in slab order.  Two slabs are in flight on the device (ndzip_hip_offloader_*).
+ * `max_elements`: 0 = the format's limit; a smaller value forces more slabs (tests, or bounding device memory). */
+
+/* the plan for `extent` (extent[0] may exceed 32 bits): rows of dimension 0 per slab, number of slabs, and the words the
+ * concatenated streams can take at most (any of the three outputs may be NULL) */
+NDZIP_HIP_API int ndzip_hip_chunked_plan(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, uint64_t *rows_per_chunk,
+        uint64_t *num_chunks, uint64_t *length_bound_words);
+
+/* `streams` must hold the plan's length bound (`capacity_words`); *total_words = words of the concatenation */
+NDZIP_HIP_API int ndzip_hip_chunked_compress(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, const void *data,
+        void *streams, uint64_t capacity_words, uint64_t *total_words, uint64_t *kernel_ns);
+
+/* every slab's header is validated (ndzip_hip_stream_words) before it is sent to the device */
+NDZIP_HIP_API int ndzip_hip_chunked_decompress(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, const void *streams,
+        uint64_t total_words, void *data, uint64_t *words_consumed, uint64_t *kernel_ns);
+
 /* ---- stage entry points (parity tests; mirror the reference's stage-level tests
  *      src/test/codec_profile_test.inl:514-549, :552-729, :735-801, :889-947) ----------------------------------- */
 

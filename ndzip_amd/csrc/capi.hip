@@ -811,6 +811,180 @@ int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, 
     return NDZIP_HIP_OK;
 }
 
+// ---- arrays beyond the format's 32-bit counts: one stream per slab of dimension 0 -----------------------------------------
+
+}  // extern "C"
+
+namespace {
+struct chunk_plan {
+    uint64_t rows_per_chunk = 0;  // rows of dimension 0 per slab (a multiple of the hypercube side, except in a single-slab plan)
+    uint64_t num_chunks = 0;
+    uint64_t rest = 1;            // elements per row of dimension 0
+};
+
+// The fewest slabs of whole hypercube rows such that every slab is a legal ndzip array: fewer than `max_elements` elements
+// (0 = the format's 2^32 - 1, ndzip.hh:20) and a length bound of at most 2^32 - 1 words.
+int plan_chunks(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, chunk_plan *plan) {
+    if (!valid_dtype(dtype) || !extent || !plan) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
+    const uint64_t limit = max_elements ? max_elements : 0xffffffffull;
+    uint64_t rest = 1;
+    for (int d = 1; d < dims; ++d) {
+        if (extent[d] > 0xffffffffull || __builtin_mul_overflow(rest, extent[d], &rest)) return fail(NDZIP_HIP_ERR_LIMIT, "extent too large");
+    }
+    plan->rest = rest;
+    const uint64_t side = side_for_dims(dims);
+    uint64_t total = 0;
+    const bool fits = !__builtin_mul_overflow(rest, extent[0], &total) && total <= limit && extent[0] <= 0xffffffffull;
+    if (fits) {
+        uint32_t e32[3] = {static_cast<uint32_t>(extent[0]), dims > 1 ? static_cast<uint32_t>(extent[1]) : 1u, dims > 2 ? static_cast<uint32_t>(extent[2]) : 1u};
+        if (length_bound(dtype, make_geom(dims, e32)) <= 0xffffffffull) {
+            plan->rows_per_chunk = extent[0];
+            plan->num_chunks = 1;
+            return NDZIP_HIP_OK;
+        }
+    }
+    if (rest == 0 || extent[0] == 0) {
+        plan->rows_per_chunk = extent[0];
+        plan->num_chunks = 1;
+        return NDZIP_HIP_OK;
+    }
+    // rows per slab: the largest multiple of the side whose elements and length bound fit (the bound is at most
+    // elements * (B + 1) / B + header, so leave that margin), at least one row of hypercubes
+    const uint64_t B = dtype == NDZIP_HIP_F32 ? 32 : 64;
+    const uint64_t budget = limit < 0xffffffffull / (B + 2) * B ? limit : 0xffffffffull / (B + 2) * B;
+    uint64_t rows = budget / rest / side * side;
+    if (rows == 0) return fail(NDZIP_HIP_ERR_LIMIT, "one row of hypercubes along dimension 0 already exceeds the format's limits");
+    const uint64_t n = (extent[0] + rows - 1) / rows;  // (the last slab takes what is left, border rows included)
+    plan->rows_per_chunk = rows;
+    plan->num_chunks = n;
+    return NDZIP_HIP_OK;
+}
+
+void chunk_extent(const chunk_plan &p, int dims, const uint64_t *extent, uint64_t k, uint32_t out[3]) {
+    const uint64_t r0 = k * p.rows_per_chunk;
+    const uint64_t rows = extent[0] - r0 < p.rows_per_chunk ? extent[0] - r0 : p.rows_per_chunk;
+    out[0] = static_cast<uint32_t>(rows);
+    out[1] = dims > 1 ? static_cast<uint32_t>(extent[1]) : 1u;
+    out[2] = dims > 2 ? static_cast<uint32_t>(extent[2]) : 1u;
+}
+}  // namespace
+
+extern "C" {
+
+int ndzip_hip_chunked_plan(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, uint64_t *rows_per_chunk, uint64_t *num_chunks,
+        uint64_t *length_bound_words) {
+    chunk_plan p;
+    if (int s = plan_chunks(dtype, dims, extent, max_elements, &p)) return s;
+    if (rows_per_chunk) *rows_per_chunk = p.rows_per_chunk;
+    if (num_chunks) *num_chunks = p.num_chunks;
+    if (length_bound_words) {
+        uint64_t total = 0;
+        for (uint64_t k = 0; k < p.num_chunks; ++k) {
+            uint32_t e[3];
+            chunk_extent(p, dims, extent, k, e);
+            total += length_bound(dtype, make_geom(dims, e));
+        }
+        *length_bound_words = total;
+    }
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_chunked_compress(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, const void *data, void *streams,
+        uint64_t capacity_words, uint64_t *total_words, uint64_t *kernel_ns) {
+    if (!streams || !total_words) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    chunk_plan p;
+    if (int s = plan_chunks(dtype, dims, extent, max_elements, &p)) return s;
+    uint32_t first[3];
+    chunk_extent(p, dims, extent, 0, first);
+    ndzip_hip_offloader *o = nullptr;
+    constexpr int slots = 2;
+    if (int s = ndzip_hip_offloader_create(dtype, dims, first, slots, &o)) return s;
+    const size_t wb = word_bytes(dtype);
+    const char *in = static_cast<const char *>(data);
+    char *out = static_cast<char *>(streams);
+    uint64_t written = 0, reserved = 0, ns_total = 0;
+    // A slab's stream goes to a provisional place (after the bounds of everything still in flight) and is moved up to its
+    // final place when it retires and its predecessors' true lengths are known.
+    struct job {
+        uint64_t provisional;  // word offset the stream was produced at
+        uint64_t bound;
+    } jobs[slots] = {};
+    int status = NDZIP_HIP_OK;
+    auto retire = [&](uint64_t k) {
+        uint32_t words = 0;
+        uint64_t ns = 0;
+        const int st = ndzip_hip_offloader_wait(o, static_cast<int>(k % slots), &words, &ns);
+        if (st) return st;
+        const job &j = jobs[k % slots];
+        if (j.provisional != written && words) memmove(out + written * wb, out + j.provisional * wb, static_cast<size_t>(words) * wb);
+        written += words;
+        ns_total += ns;
+        return static_cast<int>(NDZIP_HIP_OK);
+    };
+    for (uint64_t k = 0; k < p.num_chunks && !status; ++k) {
+        if (k >= slots) status = retire(k - slots);
+        if (status) break;
+        uint32_t e[3];
+        chunk_extent(p, dims, extent, k, e);
+        const uint64_t bound = length_bound(dtype, make_geom(dims, e));
+        // everything still in flight was reserved behind `written` at submit time; keep reserving behind the furthest
+        if (reserved < written) reserved = written;
+        if (reserved + bound > capacity_words) {
+            status = fail(NDZIP_HIP_ERR_CAPACITY, "stream buffer smaller than ndzip_hip_chunked_plan's length bound");
+            break;
+        }
+        jobs[k % slots] = {reserved, bound};
+        status = ndzip_hip_offloader_submit_compress(o, static_cast<int>(k % slots), e, in + k * p.rows_per_chunk * p.rest * wb, out + reserved * wb);
+        reserved += bound;
+    }
+    for (uint64_t k = p.num_chunks > slots ? p.num_chunks - slots : 0; k < p.num_chunks && !status; ++k) status = retire(k);
+    ndzip_hip_offloader_destroy(o);
+    if (status) return status;
+    *total_words = written;
+    if (kernel_ns) *kernel_ns = ns_total;
+    return NDZIP_HIP_OK;
+}
+
+int ndzip_hip_chunked_decompress(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, const void *streams, uint64_t total_words,
+        void *data, uint64_t *words_consumed, uint64_t *kernel_ns) {
+    if (!streams) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
+    chunk_plan p;
+    if (int s = plan_chunks(dtype, dims, extent, max_elements, &p)) return s;
+    uint32_t first[3];
+    chunk_extent(p, dims, extent, 0, first);
+    ndzip_hip_offloader *o = nullptr;
+    constexpr int slots = 2;
+    if (int s = ndzip_hip_offloader_create(dtype, dims, first, slots, &o)) return s;
+    const size_t wb = word_bytes(dtype);
+    const char *in = static_cast<const char *>(streams);
+    char *out = static_cast<char *>(data);
+    uint64_t consumed = 0, ns_total = 0;
+    int status = NDZIP_HIP_OK;
+    auto retire = [&](uint64_t k) {
+        uint64_t ns = 0;
+        const int st = ndzip_hip_offloader_wait(o, static_cast<int>(k % slots), nullptr, &ns);
+        ns_total += ns;
+        return st;
+    };
+    for (uint64_t k = 0; k < p.num_chunks && !status; ++k) {
+        if (k >= slots) status = retire(k - slots);
+        if (status) break;
+        uint32_t e[3], words = 0;
+        chunk_extent(p, dims, extent, k, e);
+        status = ndzip_hip_stream_words(dtype, dims, e, in + consumed * wb, total_words - consumed, &words);
+        if (status) break;
+        status = ndzip_hip_offloader_submit_decompress(o, static_cast<int>(k % slots), e, in + consumed * wb, words, out + k * p.rows_per_chunk * p.rest * wb);
+        consumed += words;
+    }
+    for (uint64_t k = p.num_chunks > slots ? p.num_chunks - slots : 0; k < p.num_chunks && !status; ++k) status = retire(k);
+    ndzip_hip_offloader_destroy(o);
+    if (status) return status;
+    if (words_consumed) *words_consumed = consumed;
+    if (kernel_ns) *kernel_ns = ns_total;
+    return NDZIP_HIP_OK;
+}
+
 int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in, void *d_out,
         uint32_t *d_out_len, uint32_t n, void *hip_stream) {
     if (!valid_dtype(dtype) || !valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");

@@ -72,6 +72,9 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_offloader_submit_decompress",
     "ndzip_hip_offloader_wait",
     "ndzip_hip_stream_words",
+    "ndzip_hip_chunked_plan",
+    "ndzip_hip_chunked_compress",
+    "ndzip_hip_chunked_decompress",
     "ndzip_hip_debug_stage",
 )
 
@@ -133,6 +136,10 @@ def _bind(L):
     L.ndzip_hip_offloader_submit_decompress.argtypes = [C.c_void_p, C.c_int, _U32P, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ndzip_hip_offloader_wait.argtypes = [C.c_void_p, C.c_int, _U32P, C.POINTER(C.c_uint64)]
     L.ndzip_hip_stream_words.argtypes = [C.c_int, C.c_int, _U32P, C.c_void_p, C.c_uint64, _U32P]
+    _U64P = C.POINTER(C.c_uint64)
+    L.ndzip_hip_chunked_plan.argtypes = [C.c_int, C.c_int, _U64P, C.c_uint64, _U64P, _U64P, _U64P]
+    L.ndzip_hip_chunked_compress.argtypes = [C.c_int, C.c_int, _U64P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, _U64P, _U64P]
+    L.ndzip_hip_chunked_decompress.argtypes = [C.c_int, C.c_int, _U64P, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, _U64P, _U64P]
     L.ndzip_hip_debug_stage.argtypes = [C.c_int, C.c_int, C.c_int, _U32P, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name != "ndzip_hip_last_error":
@@ -356,6 +363,41 @@ def stream_words(dtype, extent, stream: np.ndarray) -> int:
     n = C.c_uint32(0)
     _check(lib().ndzip_hip_stream_words(_dtype_code(dtype), len(extent), _ext(extent), stream.ctypes.data, stream.size, C.byref(n)))
     return n.value
+
+
+def _ext64(extent):
+    extent = [int(x) for x in extent]
+    if not 1 <= len(extent) <= 3:
+        raise NdzipHipError(ERR_INVALID_ARGUMENT, "Invalid dimensionality")
+    return (C.c_uint64 * 3)(*(extent + [1] * (3 - len(extent))))
+
+
+def chunked_plan(dtype, extent, max_elements: int = 0):
+    """-> (rows_per_chunk, num_chunks, length_bound_words) of ndzip_hip_chunked_*: arrays beyond the format's uint32 counts are
+    cut along dimension 0 into independent streams (the reference tool's multi-array file format, compress.cc:34-45)."""
+    rows, n, bound = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _check(lib().ndzip_hip_chunked_plan(_dtype_code(dtype), len(extent), _ext64(extent), int(max_elements), C.byref(rows), C.byref(n), C.byref(bound)))
+    return rows.value, n.value, bound.value
+
+
+def chunked_compress(data: np.ndarray, max_elements: int = 0) -> np.ndarray:
+    data = np.ascontiguousarray(data)
+    _, _, bound = chunked_plan(data.dtype, data.shape, max_elements)
+    out = np.zeros(max(1, bound), dtype=word_dtype(data.dtype))
+    total, ns = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().ndzip_hip_chunked_compress(_dtype_code(data.dtype), data.ndim, _ext64(data.shape), int(max_elements), data.ctypes.data,
+                                             out.ctypes.data, out.size, C.byref(total), C.byref(ns)))
+    return out[: total.value].copy()
+
+
+def chunked_decompress(streams: np.ndarray, dtype, extent, max_elements: int = 0):
+    streams = np.ascontiguousarray(streams, dtype=word_dtype(dtype))
+    out = np.zeros(tuple(int(x) for x in extent), dtype=dtype)
+    consumed, ns = C.c_uint64(0), C.c_uint64(0)
+    buf = streams if streams.size else np.zeros(1, dtype=streams.dtype)
+    _check(lib().ndzip_hip_chunked_decompress(_dtype_code(dtype), len(extent), _ext64(extent), int(max_elements), buf.ctypes.data, streams.size,
+                                               out.ctypes.data, C.byref(consumed), C.byref(ns)))
+    return out, consumed.value
 
 
 class PinnedBuffer:

@@ -29,9 +29,10 @@ def cli(hiplib):
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{np.dtype(c[0]).name}-{len(c[1])}d-x{c[2]}")
-@pytest.mark.parametrize("slots", [1, 3])
-def test_cli_files_are_the_reference_tools_files(cli, cuda_device, tmp_path, case, slots):
+@pytest.mark.parametrize("slots,mmap", [(1, True), (3, True), (3, False)], ids=["1slot-mmap", "3slots-mmap", "3slots-stdio"])
+def test_cli_files_are_the_reference_tools_files(cli, cuda_device, tmp_path, case, slots, mmap):
     dtype, shape, n = case
+    io = [] if mmap else ["--no-mmap"]  # src/io/io.cc: mapped files by default, stdio with --no-mmap (and for pipes)
     chunks = _chunks(dtype, shape, n)
     raw = tmp_path / "in.bin"
     np.concatenate([c.reshape(-1) for c in chunks]).tofile(raw)
@@ -39,7 +40,7 @@ def test_cli_files_are_the_reference_tools_files(cli, cuda_device, tmp_path, cas
     size = [str(x) for x in shape]
     t = "float" if dtype == np.float32 else "double"
     ndz, back = tmp_path / "out.ndz", tmp_path / "back.bin"
-    r = subprocess.run([cli, "-n", *size, "-t", t, "-e", "hip", "-i", str(raw), "-o", str(ndz), "--slots", str(slots)], capture_output=True,
+    r = subprocess.run([cli, "-n", *size, "-t", t, "-e", "hip", "-i", str(raw), "-o", str(ndz), "--slots", str(slots), *io], capture_output=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     assert b"ratio = " in r.stderr and (n == 1 or f"({n} chunks".encode() in r.stderr)
@@ -49,7 +50,7 @@ def test_cli_files_are_the_reference_tools_files(cli, cuda_device, tmp_path, cas
     r = subprocess.run([cli, "-d", "-n", *size, "-t", t, "--slots", str(slots)], input=want.tobytes(), capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     assert same_bits(np.frombuffer(r.stdout, dtype=dtype), np.concatenate([c.reshape(-1) for c in chunks]))
-    r = subprocess.run([cli, "-d", "-n", *size, "-t", t, "-i", str(ndz), "-o", str(back)], capture_output=True, timeout=300)
+    r = subprocess.run([cli, "-d", "-n", *size, "-t", t, "-i", str(ndz), "-o", str(back), *io], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     assert same_bits(np.fromfile(back, dtype=dtype), np.concatenate([c.reshape(-1) for c in chunks]))
 

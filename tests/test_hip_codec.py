@@ -203,3 +203,21 @@ def test_compressor_reuse_and_capacity(hiplib, cuda_device):
         comp.compress(d_in, (64 * 4, 64 * 4), d_out, d_len)
     with pytest.raises(ndzip_amd.NdzipHipError, match="dimensionality"):
         comp.compress(d_in, (4096,), d_out, d_len)
+
+
+@pytest.mark.parametrize("dtype,shape,limit", [(np.float32, (16 * 7 + 3, 32, 16), 16 * 2 * 32 * 16 + 100), (np.float64, (64 * 5, 64 * 2), 64 * 64 * 2 + 1),
+                                              (np.float32, (4096 * 6 + 77,), 4096 * 2 + 5)])
+def test_chunked_interface_for_arrays_beyond_the_format_limits(hiplib, cuda_device, dtype, shape, limit):
+    """ndzip_hip_chunked_*: one independent stream per slab of dimension 0, concatenated (the reference tool's multi-array
+    file format, compress.cc:34-45), with the element limit lowered so that small arrays need several slabs."""
+    from ndzip_amd import hip
+    from ndzip_amd.synth import synth_numpy
+
+    data = synth_numpy(shape, dtype, seed=21, noise_mask=0xFFF)
+    rows, n, bound = hip.chunked_plan(dtype, shape, limit)
+    assert n > 1
+    want = np.concatenate([oracle.compress(data[k * rows: (k + 1) * rows]) for k in range(n)])
+    got = hip.chunked_compress(data, limit)
+    assert len(got) == len(want) and np.array_equal(got, want)
+    back, consumed = hip.chunked_decompress(want, dtype, shape, limit)
+    assert consumed == len(want) and same_bits(back, data)

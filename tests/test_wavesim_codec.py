@@ -233,3 +233,41 @@ def test_lookback_timeout_stays_in_bounds_and_is_reported():
                 break
         comp.close()
     assert saw_timeout, "the spin-limit-0 variant never had to wait for a predecessor in 20 attempts"
+
+
+@pytest.mark.parametrize("dtype,shape,limit", [(np.float32, (16 * 7 + 3, 32, 16), 16 * 2 * 32 * 16 + 100), (np.float64, (64 * 5, 64 * 2), 64 * 64 * 2 + 1),
+                                              (np.float32, (4096 * 6 + 77,), 4096 * 2 + 5), (np.float32, (48, 32, 32), 0)])
+def test_chunked_interface_for_arrays_beyond_the_format_limits(dtype, shape, limit):
+    """ndzip_hip_chunked_*: dimension 0 cut into slabs of whole hypercube rows, one independent stream per slab, concatenated
+    (the reference tool's multi-array file format) -- with the element limit lowered so that small arrays need several slabs."""
+    data = synth_numpy(shape, dtype, seed=21, noise_mask=0xFFF)
+    with sim.active():
+        rows, n, bound = hip.chunked_plan(dtype, shape, limit)
+        side = SIDE[len(shape)]
+        rest = int(np.prod(shape[1:], dtype=np.int64))
+        if limit == 0:
+            assert (rows, n) == (shape[0], 1)
+        else:
+            assert rows % side == 0 and rows * rest <= limit and n == -(-shape[0] // rows) and n > 1
+        want = np.concatenate([oracle.compress(data[k * rows: (k + 1) * rows]) for k in range(n)])
+        assert bound >= len(want)
+        got = hip.chunked_compress(data, limit)
+        assert len(got) == len(want) and np.array_equal(got, want)
+        back, consumed = hip.chunked_decompress(want, dtype, shape, limit)
+        assert consumed == len(want) and same_bits(back, data)
+        with pytest.raises(hip.NdzipHipError):
+            hip.chunked_decompress(want[:-1], dtype, shape, limit)
+
+
+def test_chunked_plan_at_the_real_limits():
+    """Host-only arithmetic: 16 GiB of float32 (2^32 elements) and larger extents split into legal slabs."""
+    with sim.active():
+        rows, n, bound = hip.chunked_plan(np.float32, (4096, 1024, 1024), 0)  # 2^32 elements: one too many for index_type
+        assert n == 2 and rows % 16 == 0 and rows * 1024 * 1024 < 2 ** 32 and rows * n >= 4096
+        assert bound < 2 * 2 ** 32
+        rows, n, _ = hip.chunked_plan(np.float64, (1 << 36,), 0)
+        assert rows % 4096 == 0 and rows < 2 ** 32 and n == -(-(1 << 36) // rows)
+        rows, n, _ = hip.chunked_plan(np.float32, (2048, 1024, 1024), 0)  # 2^31 elements fit
+        assert (rows, n) == (2048, 1)
+        with pytest.raises(hip.NdzipHipError):
+            hip.chunked_plan(np.float32, (64, 1 << 20, 1 << 20), 0)  # one row of hypercubes is already too large
