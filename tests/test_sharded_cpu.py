@@ -1,6 +1,8 @@
-"""CPU suite for the multi-GPU path: shard planning and, with two gloo processes, the offset exchange +
-header gather.  The per-rank codec is the ORACLE here (this is a test of the host logic), the collectives are the very
-functions the GPU path uses (the length all-gather, ndzip_amd.sharded.base_from_lengths / gather_headers / assemble_stream)."""
+"""CPU suite for the multi-GPU path: shard planning and, with two or three gloo processes, the offset
+exchange + header gather -- (1) with the ORACLE as the per-rank codec (a test of the host logic: the length all-gather,
+ndzip_amd.sharded.base_from_lengths / gather_headers / assemble_stream) and (2) with the real per-rank driver
+ndzip_amd.sharded.ShardedCodec, its kernels (compress_split, offset_header_gathered, decompress_split) running on the wave64
+functional model of tests/wavesim."""
 import os
 import socket
 
@@ -86,5 +88,63 @@ def test_two_rank_gloo_exchange_reproduces_single_stream(tmp_path, extent, dtype
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     assert np.array_equal(parts[0]["header"], parts[1]["header"]), "every rank must hold the same global header"
     assert int(parts[0]["base"]) == 0 and int(parts[1]["base"]) == len(parts[0]["body"]) - shards[0].border
+    got = assemble_stream(dtype, extent, parts[0]["header"], [p["body"] for p in parts], [len(p["body"]) for p in parts], shards)
+    assert len(got) == len(want) and np.array_equal(got, want)
+
+
+def _model_rank_main(rank, world, port, extent, dtype_name, out_dir, async_gather):
+    """One rank of the REAL per-rank driver (ndzip_amd.sharded.ShardedCodec: compress_split kernel, length all-gather,
+    offset_header_gathered kernel, header all-gather, decompress_split kernel) with the kernels running on the wave64
+    functional model (tests/wavesim, test infrastructure) and gloo standing in for RCCL."""
+    import torch
+    import torch.distributed as dist
+
+    from ndzip_amd.sharded import ShardedCodec
+    from tests.wavesim import sim
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dtype = np.dtype(dtype_name)
+    wdt = np.uint32 if dtype.itemsize == 4 else np.uint64
+    full = synth_numpy(extent, dtype.type, seed=77, noise_mask=0xFF)
+    with sim.active():
+        codec = ShardedCodec(dtype, extent, rank, world, torch.device("cpu"), async_header_gather=async_gather)
+        sh = codec.shard
+        local = torch.from_numpy(np.ascontiguousarray(full[sh.start0: sh.start0 + sh.extent[0]]))
+        out = torch.zeros_like(local)
+        for _ in range(3):  # the handle is reused: epochs, ticket reset, pending gathers
+            codec.compress(local)
+            codec.decompress(out)
+        codec.check()
+        n = int(codec.body_len.numpy().view(np.uint32)[0])
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), header=codec.header_global.numpy().view(np.uint32).copy(),
+                 body=codec.body[:n].numpy().view(wdt).copy(), base=int(codec.base32.numpy().view(np.uint32)[0]),
+                 roundtrip=bool(np.array_equal(out.numpy().view(wdt), local.numpy().view(wdt))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("extent,dtype,world,async_gather", [((64, 48, 32), np.float32, 2, False), ((130, 200), np.float64, 2, True),
+                                                           ((50, 37, 41), np.float32, 2, False), ((6 * 4096 + 5,), np.float64, 3, True),
+                                                           ((96, 32, 32), np.float32, 3, False)])
+def test_sharded_codec_on_the_model_over_gloo(tmp_path, extent, dtype, world, async_gather):
+    import torch.multiprocessing as mp
+
+    from tests.wavesim import build as simbuild
+
+    simbuild.build()  # once, before the ranks race for it
+    port = _free_port()
+    mp.spawn(_model_rank_main, args=(world, port, extent, np.dtype(dtype).name, str(tmp_path), async_gather), nprocs=world, join=True)
+    full = synth_numpy(extent, dtype, seed=77, noise_mask=0xFF)
+    want = oracle.compress(full)
+    shards = plan_shards(extent, world)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert all(bool(p["roundtrip"]) for p in parts), "a rank's decompress_split did not reproduce its slab"
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["header"], p["header"]), "every rank must hold the same global header"
+    base = 0
+    for p, s in zip(parts, shards):
+        assert int(p["base"]) == base
+        base += len(p["body"]) - s.border
     got = assemble_stream(dtype, extent, parts[0]["header"], [p["body"] for p in parts], [len(p["body"]) for p in parts], shards)
     assert len(got) == len(want) and np.array_equal(got, want)
