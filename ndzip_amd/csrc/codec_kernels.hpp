@@ -133,10 +133,16 @@ struct __attribute__((packed, aligned(4))) unaligned16 {
 struct __attribute__((packed, aligned(4))) unaligned8 {
     u32x2_t v;
 };
+// Array input is read exactly once per launch: the aligned path uses the read-once (nt) policy (gfx950_lds.hpp); build with
+// -DNDZIP_PLAIN_INPUT_LOADS to A/B against the default cache policy.
 template<bool Aligned>
 NDZIP_DEV vec16 global_load16(const void *p) {
     if constexpr (Aligned) {
+#ifdef NDZIP_PLAIN_INPUT_LOADS
         return *reinterpret_cast<const vec16 *>(p);
+#else
+        return global_load16_once(p);
+#endif
     } else {
         const u32x4_t q = reinterpret_cast<const unaligned16 *>(p)->v;
         vec16 v;
