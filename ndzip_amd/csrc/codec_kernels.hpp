@@ -293,13 +293,26 @@ NDZIP_DEV uint64_t group8_shift_up(uint64_t v, uint32_t keep) {
     return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
-NDZIP_DEV uint32_t wave_inclusive_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+// Inclusive prefix sum over the 64 lanes with DPP: four row shifts (lanes shifted in from outside a 16-lane row read as 0)
+// scan each row, row_bcast:15 adds the total of row 0 / 2 to row 1 / 3, row_bcast:31 the total of rows 0-1 to rows 2-3 --
+// six VALU additions with no LDS round trip.  (__shfl_up compiles to ds_bpermute_b32 plus index arithmetic and a select
+// per step: six DEPENDENT LDS-crossbar round trips, ~700 cycles, on the path to the aggregate publish.)
+template<int Ctrl, int RowMask>
+NDZIP_DEV uint32_t dpp_or_zero(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), Ctrl, RowMask, 0xf, false));
+}
+NDZIP_DEV uint32_t wave_inclusive_scan(uint32_t v, int /* lane */) {
+    v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
+}
+// sum over the 64 lanes, wave-uniform (the scan's last lane)
+NDZIP_DEV uint32_t wave_sum(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_scan(v, 0)), 63));
 }
 
 template<typename W>

@@ -102,12 +102,6 @@ NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid,
     }
 }
 
-NDZIP_DEV uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
 // ---- decoupled look-back over tile lengths ---------------------------------------------------------------------
 // A tile publishes its length (aggregate) as soon as its chunk scan is done, keeps working, and only later
 // resolves its exclusive prefix by walking back over the predecessors (nearest first, 256 per hop) until a tile

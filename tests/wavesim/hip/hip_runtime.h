@@ -141,6 +141,7 @@ inline uint32_t wavesim_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
     static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | static_cast<uint64_t>(lo)) >> ((sh) & 31u))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bctrl) \
     static_cast<int>(wavesim::update_dpp(static_cast<uint32_t>(old), static_cast<uint32_t>(src), (ctrl), (rmask), (bmask), (bctrl)))
+#define __builtin_amdgcn_readlane(v, lane) static_cast<int>(wavesim_shfl_src(static_cast<uint32_t>(v), (lane) & 63))
 #define __builtin_amdgcn_sched_barrier(x) ((void) 0)
 #define __builtin_amdgcn_s_sleep(x) wavesim::sleep_hint()
 
