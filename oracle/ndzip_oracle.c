@@ -6,7 +6,7 @@
  * provide the `cpu_baseline` leg of bench.py.  Nothing under ndzip_amd/ may import, link or call it;
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
  *
- * Pinning: tests/test_oracle_golden.py checks this oracle bit-for-bit against
+ * Pinning: tests/test_oracle.py checks this oracle bit-for-bit against
  *   (a) the known-answer vectors the reference's own tests hold (for_each_border_slice lists,
  *       src/test/codec_generic_test.cc:102-111) and
  *   (b) streams produced by the reference itself, compiled from /root/reference by oracle/Makefile into
