@@ -111,5 +111,36 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     return CLI_OUT
 
 
+TEST_VARIANT_SPIN0 = os.path.join(HERE, "_variants", "spin0.so")
+
+
+def build_test_variants(force: bool = False, verbose: bool = False) -> str:
+    """ndzip_amd/_variants/spin0.so: the same library with a look-back spin limit of 0 (any wait for a predecessor is a
+    timeout), for the GPU test of the give-up path (tests/test_hip_stress.py).  Test infrastructure; never loaded by the package."""
+    out = TEST_VARIANT_SPIN0
+    objdir = os.path.join(HERE, "_variants", "obj_spin0")
+    os.makedirs(objdir, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".inl"))] + [os.path.abspath(__file__)]
+    if not force and not _stale(out, deps):
+        return out
+    jobs, objs = [], []
+    for src in SOURCES:
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        jobs.append([HIPCC, *FLAGS, "-DNDZIP_LOOKBACK_SPIN_LIMIT=0", "-c", os.path.join(CSRC, src), "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        list(ex.map(run, jobs))
+    run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out, *objs])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -99,3 +99,61 @@ def test_concurrent_compressors_on_separate_streams(hiplib, cuda_device, dtype):
             assert n == len(wants[i]) and np.array_equal(got, wants[i]), (round_, i)
     for c in comps:
         c.close()
+
+
+_TIMEOUT_SCRIPT = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[2])
+from ndzip_amd import hip
+hip.LIB_PATH = sys.argv[1]           # the spin-limit-0 build, in a process of its own
+from ndzip_amd.synth import synth_numpy
+shape_big, shape = (96, 256, 256), (32, 256, 256)
+big = torch.from_numpy(synth_numpy(shape_big, np.float32, seed=1, noise_mask=0xFFFF)).cuda()
+small = torch.from_numpy(synth_numpy(shape, np.float32, seed=2, noise_mask=0xFFFF)).cuda()
+comp = hip.make_hip_compressor(np.float32, hip.CompressorRequirements(shape_big))
+bound_big, bound = hip.compressed_length_bound(np.float32, shape_big), hip.compressed_length_bound(np.float32, shape)
+out_big = torch.zeros(bound_big, dtype=torch.int32, device="cuda")
+length = torch.zeros(1, dtype=torch.int32, device="cuda")
+timeouts = 0
+for attempt in range(10):
+    comp.compress(big, shape_big, out_big, length)
+    try:
+        comp.check()
+    except hip.NdzipHipError:
+        pass
+    out = torch.full((bound + 65536,), 0x5EADBEEF, dtype=torch.int32, device="cuda")
+    length.fill_(12345)
+    comp.compress(small, shape, out, length)
+    torch.cuda.synchronize()
+    assert bool((out[bound:] == 0x5EADBEEF).all()), "a write went past the caller's stream buffer"
+    try:
+        comp.check()
+    except hip.NdzipHipError as e:
+        assert "look-back timeout" in str(e), str(e)
+        assert int(length.cpu()[0]) == 0, "a timed-out launch must poison the stream length"
+        timeouts += 1
+print("TIMEOUTS", timeouts)
+"""
+
+
+def test_lookback_timeout_is_contained(hiplib, cuda_device, tmp_path):
+    """The look-back's give-up path on hardware: a build with a spin limit of 0 (every wait for a predecessor is a timeout),
+    after a LARGER launch on the same handle (stale descriptors of another epoch in the scratch).  Every write must stay inside
+    the caller's buffer (canary), check() must report the timeout and the stream length must be poisoned.  Runs in a process of
+    its own so that a memory fault -- the round-1 symptom of this path -- fails this test instead of the whole suite."""
+    import os
+    import subprocess
+    import sys
+
+    from ndzip_amd import build
+
+    lib = build.TEST_VARIANT_SPIN0
+    if not os.path.exists(lib):
+        lib = build.build_test_variants()
+    script = tmp_path / "timeout_case.py"
+    script.write_text(_TIMEOUT_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), lib, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "TIMEOUTS" in r.stdout and int(r.stdout.split("TIMEOUTS")[1].split()[0]) > 0, "the spin-limit-0 build never timed out"
