@@ -271,3 +271,19 @@ def test_chunked_plan_at_the_real_limits():
         assert (rows, n) == (2048, 1)
         with pytest.raises(hip.NdzipHipError):
             hip.chunked_plan(np.float32, (64, 1 << 20, 1 << 20), 0)  # one row of hypercubes is already too large
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+@pytest.mark.parametrize("schedule", ["reverse", "random:1", "random:2", "random:3"])
+def test_result_does_not_depend_on_the_order_work_items_run_in(profile, schedule):
+    """Between two synchronisation points the model runs a workgroup's work-items one after the other; a kernel without
+    intra-workgroup races gives the same stream whatever that order is (forward in every other test; reversed and shuffled
+    here).  An order-dependent result = a missing barrier."""
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 7 + 3,), 2: (side * 3, side * 2 + 5), 3: (side * 2, side * 2 + 1, side * 2)}[dims]
+    data = synth_numpy(shape, dtype, seed=31, noise_mask=0xFFF)
+    want = oracle.compress(data)
+    got = sim.compress(data, cus=3, blocks_per_cu=2, schedule=schedule)
+    assert len(got) == len(want) and np.array_equal(got, want)
+    assert same_bits(sim.decompress(want, dtype, shape, schedule=schedule), data)

@@ -22,12 +22,14 @@ def load(variant: str = "", defines=()):
 
 
 @contextlib.contextmanager
-def active(cus: int = 2, blocks_per_cu: int = 2, variant: str = ""):
-    """Route ndzip_amd.hip's ctypes calls to the model for the duration of the block (tests only: the product never does)."""
+def active(cus: int = 2, blocks_per_cu: int = 2, variant: str = "", schedule: str = ""):
+    """Route ndzip_amd.hip's ctypes calls to the model for the duration of the block (tests only: the product never does).
+    schedule: order in which a workgroup's runnable work-items are resumed: "" (forward), "reverse", "random:<seed>"."""
     L = load(variant)
-    saved, env = hip._lib, {k: os.environ.get(k) for k in ("WAVESIM_CUS", "WAVESIM_BLOCKS_PER_CU")}
+    saved, env = hip._lib, {k: os.environ.get(k) for k in ("WAVESIM_CUS", "WAVESIM_BLOCKS_PER_CU", "WAVESIM_SCHEDULE")}
     os.environ["WAVESIM_CUS"] = str(cus)
     os.environ["WAVESIM_BLOCKS_PER_CU"] = str(blocks_per_cu)
+    os.environ["WAVESIM_SCHEDULE"] = schedule
     hip._lib = L
     try:
         yield L
@@ -44,10 +46,10 @@ def _words(dtype):
     return np.uint32 if np.dtype(dtype).itemsize == 4 else np.uint64
 
 
-def compress(data: np.ndarray, cus: int = 2, blocks_per_cu: int = 2, misalign_words: int = 0) -> np.ndarray:
+def compress(data: np.ndarray, cus: int = 2, blocks_per_cu: int = 2, misalign_words: int = 0, schedule: str = "") -> np.ndarray:
     """Device-pointer compress (ndzip_hip_compressor_compress) on the model; returns the stream words."""
     data = np.ascontiguousarray(data)
-    with active(cus, blocks_per_cu):
+    with active(cus, blocks_per_cu, schedule=schedule):
         bound = hip.compressed_length_bound(data.dtype, data.shape)
         out = np.zeros(max(1, bound) + 8, dtype=_words(data.dtype))
         length = np.zeros(1, dtype=np.uint32)
@@ -62,10 +64,10 @@ def compress(data: np.ndarray, cus: int = 2, blocks_per_cu: int = 2, misalign_wo
     return out[misalign_words:misalign_words + n].copy()
 
 
-def decompress(stream: np.ndarray, dtype, extent, bounded: bool = False) -> np.ndarray:
+def decompress(stream: np.ndarray, dtype, extent, bounded: bool = False, schedule: str = "") -> np.ndarray:
     stream = np.ascontiguousarray(stream)
     out = np.zeros(extent, dtype=dtype)
-    with active():
+    with active(schedule=schedule):
         dec = hip.make_hip_decompressor(dtype, len(extent))
         try:
             buf = stream if stream.size else np.zeros(1, dtype=_words(dtype))

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <sys/mman.h>
 
+#include <algorithm>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -173,9 +174,25 @@ void run_workgroup(unsigned block_idx, launch_cfg cfg, void (*fn)(void *), void 
         l.stack = stacks.get(t);
         prepare_fiber(l);
     }
+    // Order in which runnable work-items are resumed within a pass (WAVESIM_SCHEDULE): forward (default), reverse, or
+    // random:<seed> (a fresh permutation per pass).  A kernel that is correct on hardware gives the same result under every
+    // order -- whatever differs between orders is a missing barrier or an intra-workgroup race.
+    const char *sched = getenv("WAVESIM_SCHEDULE");
+    const bool reverse = sched && strcmp(sched, "reverse") == 0;
+    const bool random = sched && strncmp(sched, "random", 6) == 0;
+    uint64_t rng = 0x9e3779b97f4a7c15ull * (block_idx + 1) + (random && sched[6] == ':' ? strtoull(sched + 7, nullptr, 10) : 0);
+    std::vector<unsigned> order(cfg.block);
+    for (unsigned t = 0; t < cfg.block; ++t) order[t] = reverse ? cfg.block - 1 - t : t;
     while (wg.alive > 0) {
         bool progressed = false;
-        for (lane_ctx &l : wg.lanes) {
+        if (random) {
+            for (unsigned i = cfg.block - 1; i > 0; --i) {
+                rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17;
+                std::swap(order[i], order[rng % (i + 1)]);
+            }
+        }
+        for (unsigned idx : order) {
+            lane_ctx &l = wg.lanes[idx];
             if (l.done) continue;
             if (l.wait_on) {
                 if (*l.wait_on == l.wait_val) continue;
