@@ -152,3 +152,37 @@ def test_file_tool_rejects_partial_and_corrupt_input(model_cli, tmp_path):
         blob.tofile(f)
         r = run(model_cli, "-d", "-n", "8192", "-i", str(f), "-o", str(tmp_path / "b.bin"))
         assert r.returncode != 0 and msg in r.stderr, r.stderr
+
+
+def test_benchmark_tool_on_the_model(tmp_path):
+    """ndzip-hip-benchmark (the `ndzip-hip` rows of the reference's result CSV, benchmark.cc:1332-1337,1487-1489) linked against the
+    functional model: dataset CSV in, header and one row per dataset out, sizes against the oracle, round trip verified by the tool."""
+    from ndzip_amd.synth import synth_numpy
+    from tests.wavesim import build as simbuild
+
+    lib = simbuild.build()
+    exe = str(tmp_path / "ndzip-hip-benchmark-model")
+    src = os.path.join(os.path.dirname(build.__file__), "cli", "ndzip_hip_benchmark.cc")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, src, lib, "-Wl,-rpath," + os.path.dirname(lib)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sets = [("a.f32", np.float32, (70, 130)), ("b.f64", np.float64, (16, 40, 17)), ("c.f32", np.float32, (4096 * 3 + 5,))]
+    lines, want = [], {}
+    for name, dtype, shape in sets:
+        data = synth_numpy(shape, dtype, seed=11, noise_mask=0xFF)
+        data.tofile(tmp_path / name)
+        lines.append(f"{name};{'float' if dtype == np.float32 else 'double'};{' '.join(str(x) for x in shape)}")
+        want[name] = (data.nbytes, oracle.compress(data).nbytes, len(shape))
+    (tmp_path / "sets.csv").write_text("\n".join(lines) + "\n")
+    r = subprocess.run([exe, "-r", "2", "-t", "0", str(tmp_path / "sets.csv")], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    rows = r.stdout.decode().strip().split("\n")
+    assert rows[0].split(";") == ["dataset", "data type", "dimensions", "algorithm", "tunable", "number of threads",
+                                  "compression times (microseconds)", "decompression times (microseconds)", "uncompressed bytes",
+                                  "compressed bytes"]
+    assert len(rows) == 1 + len(sets)
+    for row in rows[1:]:
+        c = row.split(";")
+        raw, comp, dims = want[c[0]]
+        assert c[1] in ("float", "double") and int(c[2]) == dims and c[3] == "ndzip-hip" and c[4] == "1" and c[5] == "1"
+        assert len(c[6].split(",")) >= 2 and len(c[7].split(",")) >= 2
+        assert int(c[8]) == raw and int(c[9]) == comp
