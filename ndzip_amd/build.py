@@ -20,6 +20,9 @@ SOURCES = ["kernels_f32.hip", "kernels_f64.hip", "capi.hip"]
 # every header a translation unit can see: a stale object for the newest kernel is the worst kind of benchmark bug
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inl"))) + ["../../include/ndzip_hip.h"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# No atomic optimizer: it rewrites the single-lane ticket atomicAdd into mbcnt + atomic + readfirstlane and waits for the
+# result on the spot, which puts the atomic's round trip back on the path the kernel takes care to hide it behind the copy-out.
+FLAGS += ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 FLAGS += os.environ.get("NDZIP_EXTRA_FLAGS", "").split()  # experiments only (tools/)
 
 

@@ -381,11 +381,18 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
-    // The first ticket has its own LDS slot: work-item 0 stores the NEXT ticket to misc[NW + 1] before the loop's first
-    // barrier, and nothing orders that store after the other wavefronts' read of the first one.
+    // Tickets.  The ticket of the tile an iteration works on was drawn a little more than one iteration earlier: the one for
+    // the first tile here (its own LDS slot), the one for the second right behind it, every later one behind B3 of the
+    // iteration before -- i.e. just before that iteration's copy-out, which hides the atomic's round trip (~1 us under a
+    // streaming load, MI355X guide "dequeue").  Drawn at the top of the iteration that consumes it behind B1 -- as round 1 had
+    // it -- that round trip sat on wavefront 0's path to B1 and with it on the whole workgroup's (built without LLVM's atomic
+    // optimizer: it turns the single-lane atomicAdd into mbcnt + atomic + readfirstlane and waits for the result at once).
+    // A whole extra tile of look-ahead was measured in round 1 and loses (0.255 vs 0.205 ms: claim order and processing order
+    // drift apart and the look-back waits); this is a quarter of an iteration.
     if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
     uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
+    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);  // (read behind the first B1)
 
 #ifdef NDZIP_EXP_PHASE_TIMING
     const bool timing = (exp_flags & 16u) != 0;
@@ -423,23 +430,20 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (!have_cur && !have_prev) break;
         const uint32_t hc = tile * K + grp;
         const bool active = have_cur && hc < gg.nhc;
-        // The previous tile's look-back window, issued together with the ticket: both return while this wavefront
-        // waits for its prefetched input anyway, so the window is in registers before any other memory operation of
-        // the iteration is issued and the resolve below needs no wait.
+        // The previous tile's look-back window: it returns while this wavefront waits for its prefetched input anyway, so
+        // the window is in registers before any other memory operation of the iteration is issued and the resolve below
+        // needs no wait.
         lookback_windows window{};
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         if (have_cur) {
-            uint32_t next_ticket = 0;
-            if (tid == 0) next_ticket = atomicAdd(ticket_counter, 1u);
             if constexpr (Paired) {
                 stage_pair_regs(pre, smem, C::cube_stride, tid);  // (an even hypercube count: both cubes of a tile exist)
             } else {
                 if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
             }
-            if (tid == 0) misc[NW + 1] = next_ticket;
         }
-        NDZIP_PHASE(0)  // ticket + wait prefetch + stage
-        __syncthreads();  // B1: cube staged, next ticket known
+        NDZIP_PHASE(0)  // wait prefetch + stage
+        __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
         const uint32_t next_tile = have_cur ? tile_of_ticket(misc[NW + 1], cls, num_classes) : tile;
         __builtin_amdgcn_sched_barrier(0);
         uint32_t next_hc = Paired ? next_tile * K : next_tile * K + grp;
@@ -523,6 +527,10 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         }
         NDZIP_PHASE(6)  // resolve (prev)
         __syncthreads();  // B3: previous tile's runs complete in LDS, its prefix known
+        // the ticket the NEXT iteration reads behind its B1 (it needs one iff it has a tile); in flight during the copy-out
+        const bool draw = tid == 0 && next_tile < ntiles;
+        uint32_t ticket_after_next = 0;
+        if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
             const uint32_t prefix = misc[NW];
             if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
@@ -530,8 +538,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             // the last tile ends the body (store_stream_length, cuda_codec.inl:507-511)
             if (tid == 0 && prev_tile == ntiles - 1) store_stream_length(out_len, len_extra + prefix + prev_aggregate);
         }
-        NDZIP_PHASE(4)  // B3 + copy-out (prev)
-        __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them
+        if (draw) misc[NW + 1] = ticket_after_next;
+        NDZIP_PHASE(4)  // B3 + ticket + copy-out (prev)
+        __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them; next ticket in LDS
         have_prev = have_cur;
         prev_tile = tile;
         prev_aggregate = aggregate;
@@ -598,11 +607,11 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     const uint32_t ntiles = gg.nhc;
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
-    // The first ticket has its own LDS slot: work-item 0 stores the NEXT ticket to misc[NW + 1] before the loop's first
-    // barrier, and nothing orders that store after the other wavefronts' read of the first one.
+    // tickets: see compress_kernel_db (first one in its own slot, every later one drawn behind the B3 before its consumer's B1)
     if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
     uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
+    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
 
     wide::input_regs<W> pre;
     wide::load_regs<W, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, tile < ntiles ? tile : ntiles - 1), t, pre);
@@ -619,13 +628,8 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         if (!have_cur && !have_prev) break;
         lookback_windows window{};
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
-        if (have_cur) {
-            uint32_t next_ticket = 0;
-            if (tid == 0) next_ticket = atomicAdd(ticket_counter, 1u);
-            wide::stage_regs<W>(pre, cube, t);
-            if (tid == 0) misc[NW + 1] = next_ticket;
-        }
-        __syncthreads();  // B1: cube staged, next ticket known
+        if (have_cur) wide::stage_regs<W>(pre, cube, t);
+        __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
         const uint32_t next_tile = have_cur ? tile_of_ticket(misc[NW + 1], cls, num_classes) : tile;
         __builtin_amdgcn_sched_barrier(0);
         const uint64_t next_origin = hc_origin<Dims>(gg, next_tile < ntiles ? next_tile : ntiles - 1);
@@ -667,6 +671,9 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
             if (tid == 0) misc[NW] = exclusive;
         }
         __syncthreads();  // B3: previous tile's run complete in LDS, its prefix known
+        const bool draw = tid == 0 && next_tile < ntiles;  // the ticket the next iteration reads behind its B1
+        uint32_t ticket_after_next = 0;
+        if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
             const uint32_t prefix = misc[NW];
             if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
@@ -679,7 +686,8 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
                 }
             }
         }
-        __syncthreads();  // B4: copy-out has read the run before the next tile is staged over it
+        if (draw) misc[NW + 1] = ticket_after_next;
+        __syncthreads();  // B4: copy-out has read the run before the next tile is staged over it; next ticket in LDS
         have_prev = have_cur;
         prev_tile = tile;
         prev_aggregate = aggregate;

@@ -7,7 +7,7 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/ndzip_amd/_variants; mkdir -p "$out/obj_$name"
 for u in kernels_f32 kernels_f64 capi; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function "$@" \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" \
       -c "$root/ndzip_amd/csrc/$u.hip" -o "$out/obj_$name/$u.o" &
 done
 wait
