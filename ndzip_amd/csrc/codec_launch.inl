@@ -430,11 +430,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (!have_cur && !have_prev) break;
         const uint32_t hc = tile * K + grp;
         const bool active = have_cur && hc < gg.nhc;
-        // The previous tile's look-back window: it returns while this wavefront waits for its prefetched input anyway, so
-        // the window is in registers before any other memory operation of the iteration is issued and the resolve below
-        // needs no wait.
-        lookback_windows window{};
-        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         if (have_cur) {
             if constexpr (Paired) {
                 stage_pair_regs(pre, smem, C::cube_stride, tid);  // (an even hypercube count: both cubes of a tile exist)
@@ -442,7 +437,15 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
                 if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
             }
         }
-        NDZIP_PHASE(0)  // wait prefetch + stage
+        // The previous tile's look-back window is read BEHIND the staging, not in front of it: the staging's wait for the
+        // last prefetched vector is an s_waitcnt vmcnt(0) (gfx9 counts loads and stores in one in-order counter, and the
+        // previous copy-out issued a data-dependent number of stores after the prefetch), so a window load issued before it
+        // is waited for in full, every iteration, by the wavefront the whole workgroup then waits for at B1 (round 1 had
+        // it there: ISA + the ~3 k cycles of its "top of the iteration" phase timer).  Issued here it is in flight until the
+        // resolve, most of an iteration later.
+        lookback_windows window{};
+        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
+        NDZIP_PHASE(0)  // wait prefetch + stage + window issue
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
         const uint32_t next_tile = have_cur ? tile_of_ticket(misc[NW + 1], cls, num_classes) : tile;
         __builtin_amdgcn_sched_barrier(0);
@@ -626,9 +629,9 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     for (;;) {
         const bool have_cur = tile < ntiles;
         if (!have_cur && !have_prev) break;
-        lookback_windows window{};
-        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         if (have_cur) wide::stage_regs<W>(pre, cube, t);
+        lookback_windows window{};  // (behind the staging: see compress_kernel_db)
+        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
         const uint32_t next_tile = have_cur ? tile_of_ticket(misc[NW + 1], cls, num_classes) : tile;
         __builtin_amdgcn_sched_barrier(0);
