@@ -14,3 +14,8 @@ run --shape 512,512,512 --dtype float32 --smooth
 run --shape 512,512,512 --dtype float32 --data zeros
 run --shape 512,512,512 --dtype float32 --data random
 run --shape 510,511,509 --dtype float32
+run --config 4
+python bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(d['config']['workload'][:60], '| ratio', d['config']['compression_ratio'], '| decompress-only', d['per_gpu']['decompress_GBps'], 'GB/s', r['launch_ms'], 'ms frac', r['frac'], '| exact', d['roundtrip_bit_exact'])"

@@ -1,0 +1,27 @@
+#!/bin/bash
+# One gpurun call's worth of evidence for a round (everything under gpurun_out/<tag>_*; copy what matters to profiles/):
+#   1. the full -m gpu suite + smoke()                         (parity)
+#   2. the default bench line                                   (the driver's command)
+#   3. every BASELINE config + bookends, one line each          (tools/bench_configs.sh)
+#   4. rocprofv3 kernel trace + PMC passes of the default bench (tools/pmc.sh)
+#   5. A/B of the read-once input loads against plain loads     (tools/ab.sh; variant built on the CPU beforehand)
+#   6. the two-processes-on-one-GPU stress of the sharded path, 6 x 40 iterations, each under its own timeout
+# usage: tools/gpu_round_batch.sh <tag>     (about 25 minutes)
+tag=${1:-rNN}
+mkdir -p gpurun_out
+O=gpurun_out/$tag
+rocminfo | grep -E "gfx|Compute Unit" | head -4 > ${O}_rocminfo.txt
+(timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -25) > ${O}_gputest.txt
+(timeout 180 python __graft_entry__.py smoke 2>&1 | tail -3) >> ${O}_gputest.txt
+timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
+(timeout 900 bash tools/bench_configs.sh 2>&1) > ${O}_configs.txt
+timeout 900 bash tools/pmc.sh ${O}_rocprofv3_summary.txt
+timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_2d.txt --config 3
+if [ -f ndzip_amd/_variants/plainloads.so ]; then (timeout 600 bash tools/ab.sh "main plainloads" 2>&1) > ${O}_ab_nt_loads.txt; fi
+for i in 1 2 3 4 5 6; do
+  echo "== run $i" >> ${O}_two_process_stress.txt
+  HSA_ENABLE_IPC_MODE_LEGACY=0 CHECK_EACH=0 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+      --master-port $((29510 + i)) tools/sharded_stress.py 40 >> ${O}_two_process_stress.txt 2>&1
+  echo "exit $?" >> ${O}_two_process_stress.txt
+done
+tail -5 ${O}_gputest.txt; cat ${O}_bench_n1.json; cat ${O}_configs.txt; tail -14 ${O}_two_process_stress.txt
