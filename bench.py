@@ -59,7 +59,7 @@ CONFIGS = {
 }
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -76,7 +76,7 @@ def parse_args():
     ap.add_argument("--compress-only", action="store_true", help="a step is the compress half only")
     ap.add_argument("--decompress-only", action="store_true", help="a step is the decompress half only (the grid is compressed once, untimed)")
     ap.add_argument("--lib", type=str, default=None, help="A/B tooling: load this build of the library instead of ndzip_amd/libndzip_hip.so")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ---- CPU legs (rank 0, N = 1 only; bounded samples; the checker's code is timed here, never shipped) -------------------------
@@ -321,8 +321,30 @@ def cpu_legs(host_grid, budget_s):
 
 # ---- the GPU benchmark ------------------------------------------------------------------------------------------------------
 
-def main():
-    args = parse_args()
+class Accelerator:
+    """The four things main() asks of torch.cuda, in one place (tests/test_bench_cpu.py substitutes a host stand-in to run
+    main() end to end against the kernels' functional model; the benchmark itself always runs on the GPU)."""
+
+    def __init__(self, index):
+        import torch
+
+        assert torch.cuda.is_available(), "bench.py needs a GPU: the ndzip HIP back-end has no CPU fallback"
+        torch.cuda.set_device(index)
+        self.device = torch.device("cuda", index)
+
+    def synchronize(self):
+        import torch
+
+        torch.cuda.synchronize()
+
+    def event(self):
+        import torch
+
+        return torch.cuda.Event(enable_timing=True)
+
+
+def main(argv=None):
+    args = parse_args(argv)
     if args.compress_only and args.decompress_only:
         raise SystemExit("--compress-only and --decompress-only exclude each other")
     import numpy as np
@@ -348,8 +370,8 @@ def main():
     # refuses two ranks on one device; same code path otherwise
     share_gpu = world > 1 and os.environ.get("NDZIP_BENCH_SHARE_GPU") == "1"
     dev_index = 0 if share_gpu else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    acc = Accelerator(dev_index)
+    device = acc.device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
@@ -393,7 +415,7 @@ def main():
 
     if mode == "decompress":  # the stream that every timed step decodes
         codec.compress(local)
-        torch.cuda.synchronize()
+        acc.synchronize()
         codec.check()
 
     def step(ev=None):
@@ -410,20 +432,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    acc.synchronize()
     codec.check()
 
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    events = [[acc.event() for _ in range(4)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    acc.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
-    torch.cuda.synchronize()
+    acc.synchronize()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    acc.synchronize()
     elapsed = time.perf_counter() - t0
     codec.check()
 
