@@ -1,3 +1,4 @@
+import contextlib
 import os
 import sys
 
@@ -8,21 +9,76 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--rehearse-on-model", action="store_true", default=False,
+                     help="run the `-m gpu` tests' CODE on the CPU against the kernels' functional model (tests/wavesim): host tensors, "
+                          "synchronous 'streams'; full-size and subprocess cases are skipped.  A rehearsal of the GPU suite in the GPU-less "
+                          "authoring container -- it is not the GPU run and proves nothing about the hardware.")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "hardware_only: a gpu test that cannot be rehearsed on the functional model (size, subprocess, real runtime)")
+    if config.getoption("--rehearse-on-model"):
+        _enter_rehearsal()
+
+
+def pytest_collection_modifyitems(config, items):
+    if not config.getoption("--rehearse-on-model"):
+        return
+    skip = pytest.mark.skip(reason="hardware only: not part of the rehearsal on the functional model")
+    for item in items:
+        if "hardware_only" in item.keywords:
+            item.add_marker(skip)
+
+
+_rehearsal = contextlib.ExitStack()
+
+
+def _enter_rehearsal():
+    """Host tensors for device tensors, the model library for the HIP library, no-op streams for torch.cuda's."""
+    import torch
+
+    from tests import util
+    from tests.wavesim import sim
+
+    _rehearsal.enter_context(sim.active(cus=3, blocks_per_cu=2))
+    util.DEVICE = "cpu"
+
+    class _Stream:
+        cuda_stream = 0
+
+        def __init__(self, *a, **k):
+            pass
+
+        def synchronize(self):
+            pass
+
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.Stream = _Stream
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.is_available = lambda: True
 
 
 @pytest.fixture(scope="session")
-def hiplib():
+def rehearsal(request):
+    return request.config.getoption("--rehearse-on-model")
+
+
+@pytest.fixture(scope="session")
+def hiplib(rehearsal):
     """The in-tree HIP library; GPU tests fail loudly (no skip, no fallback) if it is missing."""
     from ndzip_amd import hip
 
-    return hip.lib()
+    return hip.lib()  # (in a rehearsal hip._lib already is the model, see _enter_rehearsal)
 
 
 @pytest.fixture(scope="session")
-def cuda_device():
+def cuda_device(rehearsal):
     import torch
 
+    if rehearsal:
+        return torch.device("cpu")
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     return torch.device("cuda:0")

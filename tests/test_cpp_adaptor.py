@@ -38,6 +38,7 @@ def test_integration_factory_unit_compiles_in_the_reference_tree(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.hardware_only
 def test_adaptor_roundtrip_on_gpu(tmp_path):
     exe = str(tmp_path / "adaptor_rt")
     libdir = os.path.join(ROOT, "ndzip_amd")

@@ -28,6 +28,7 @@ def cli(hiplib):
     return build.build_cli()
 
 
+@pytest.mark.hardware_only  # (the binaries link the real library; tests/test_cli_cpu.py runs them linked against the model)
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{np.dtype(c[0]).name}-{len(c[1])}d-x{c[2]}")
 @pytest.mark.parametrize("slots,mmap", [(1, True), (3, True), (3, False)], ids=["1slot-mmap", "3slots-mmap", "3slots-stdio"])
 def test_cli_files_are_the_reference_tools_files(cli, cuda_device, tmp_path, case, slots, mmap):
@@ -55,6 +56,7 @@ def test_cli_files_are_the_reference_tools_files(cli, cuda_device, tmp_path, cas
     assert same_bits(np.fromfile(back, dtype=dtype), np.concatenate([c.reshape(-1) for c in chunks]))
 
 
+@pytest.mark.hardware_only
 def test_cli_rejects_partial_and_truncated_input(cli, cuda_device, tmp_path):
     raw = tmp_path / "in.bin"
     np.arange(4096 + 10, dtype=np.float32).tofile(raw)
@@ -110,6 +112,7 @@ def test_pipelined_offloader_matches_oracle(hiplib, cuda_device, case):
         b.close()
 
 
+@pytest.mark.hardware_only
 def test_benchmark_tool_writes_the_reference_result_csv(hiplib, cuda_device, tmp_path):
     """Column set and row format of src/benchmark/benchmark.cc:1332-1337,1487-1489, sizes against the oracle."""
     sets = [("a.f32", np.float32, (70, 130)), ("b.f64", np.float64, (16, 40, 17)), ("c.f32", np.float32, (4096 * 3 + 5,))]

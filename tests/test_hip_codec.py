@@ -192,9 +192,9 @@ def test_compressor_reuse_and_capacity(hiplib, cuda_device):
     comp = ndzip_amd.make_hip_compressor(np.float32, req)
     for shape in [(64 * 3, 64 * 2), (64, 64 * 5), (70, 130)]:
         data = random_unit_floats(shape, np.float32, 70)
-        d_in = torch.from_numpy(data).cuda()
-        d_out = torch.zeros(ndzip_amd.compressed_length_bound(np.float32, shape), dtype=torch.int32, device="cuda")
-        d_len = torch.zeros(1, dtype=torch.int32, device="cuda")
+        d_in = torch.from_numpy(data).to(cuda_device)
+        d_out = torch.zeros(ndzip_amd.compressed_length_bound(np.float32, shape), dtype=torch.int32, device=cuda_device)
+        d_len = torch.zeros(1, dtype=torch.int32, device=cuda_device)
         comp.compress(d_in, shape, d_out, d_len)
         comp.check()
         n = int(d_len.cpu()[0])

@@ -22,6 +22,7 @@ def _uneven_grid(shape, dtype, seed):
     return a
 
 
+@pytest.mark.hardware_only
 @pytest.mark.parametrize("dtype,shape", [(np.float32, (192, 256, 256)), (np.float64, (2048, 1536)), (np.float32, (4096 * 700,))])
 def test_compress_under_background_load(hiplib, cuda_device, dtype, shape):
     import torch
@@ -137,6 +138,7 @@ print("TIMEOUTS", timeouts)
 """
 
 
+@pytest.mark.hardware_only
 def test_lookback_timeout_is_contained(hiplib, cuda_device, tmp_path):
     """The look-back's give-up path on hardware: a build with a spin limit of 0 (every wait for a predecessor is a timeout),
     after a LARGER launch on the same handle (stale descriptors of another epoch in the scratch).  Every write must stay inside

@@ -4,6 +4,7 @@ from __future__ import annotations
 import numpy as np
 
 SIDE = {1: 4096, 2: 64, 3: 16}
+DEVICE = "cuda:0"  # where device_compress / device_decompress put their tensors (tests/conftest.py: "cpu" in a model rehearsal)
 PROFILES = [(np.float32, 1), (np.float32, 2), (np.float32, 3), (np.float64, 1), (np.float64, 2), (np.float64, 3)]
 
 
@@ -44,12 +45,13 @@ def sparse_residuals(dtype, seed=0):
     return x
 
 
-def device_compress(data: np.ndarray, device="cuda:0"):
+def device_compress(data: np.ndarray, device=None):
     """compress through the device-pointer C ABI; returns the stream (numpy words)."""
     import torch
 
     import ndzip_amd
 
+    device = device or DEVICE
     data = np.ascontiguousarray(data)
     extent = data.shape
     bound = ndzip_amd.compressed_length_bound(data.dtype, extent)
@@ -67,10 +69,12 @@ def device_compress(data: np.ndarray, device="cuda:0"):
     return out
 
 
-def device_decompress(stream: np.ndarray, dtype, extent, device="cuda:0"):
+def device_decompress(stream: np.ndarray, dtype, extent, device=None):
     import torch
 
     import ndzip_amd
+
+    device = device or DEVICE
 
     stream = np.ascontiguousarray(stream)
     n = int(np.prod(extent, dtype=np.int64))
