@@ -287,3 +287,10 @@ def test_result_does_not_depend_on_the_order_work_items_run_in(profile, schedule
     got = sim.compress(data, cus=3, blocks_per_cu=2, schedule=schedule)
     assert len(got) == len(want) and np.array_equal(got, want)
     assert same_bits(sim.decompress(want, dtype, shape, schedule=schedule), data)
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 48), (16, 48, 16), (48, 16, 80)])
+def test_f32_3d_with_an_odd_hypercube_count_along_x_takes_the_unpaired_loads(shape):
+    """Aligned rows but an odd number of hypercubes along x: tiles 2m, 2m+1 are not x-neighbours everywhere, so the launcher
+    must pick the unpaired kernel (compress_kernel_db<float, 3, true, false>)."""
+    _check(synth_numpy(shape, np.float32, seed=41, noise_mask=0xFFF), cus=3, blocks_per_cu=2)
