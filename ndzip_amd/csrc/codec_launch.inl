@@ -392,7 +392,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
     uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
-    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);  // (read behind the first B1)
 
 #ifdef NDZIP_EXP_PHASE_TIMING
     const bool timing = (exp_flags & 16u) != 0;
@@ -418,6 +417,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (first_hc >= gg.nhc) first_hc = gg.nhc - 1;
         load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, first_hc), t, pre);
     }
+    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);  // second ticket, behind the first tile's loads; read behind the first B1
     // the previous tile: transposed planes in registers, aggregate published, waiting for its prefix
     bool have_prev = false, prev_active = false;
     uint32_t prev_tile = 0, prev_aggregate = 0, prev_run_start = 0, prev_my_len = 0, prev_chunk_excl = 0, prev_hc = 0;
@@ -614,10 +614,10 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
     uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
-    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);
 
     wide::input_regs<W> pre;
     wide::load_regs<W, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, tile < ntiles ? tile : ntiles - 1), t, pre);
+    if (tid == 0) misc[NW + 1] = atomicAdd(ticket_counter, 1u);  // second ticket, behind the first tile's loads
 
     // the previous tile: this lane's plane words in registers, aggregate published, waiting for its prefix
     bool have_prev = false;
