@@ -581,9 +581,11 @@ NDZIP_DEV void write_planes32(uint32_t *run, uint32_t run_word0, int t, uint32_t
             lds_write16(dst + 16 * i, v);
         }
     } else {
+        // (a running pointer, not a running index: one address increment per kept plane instead of index + shift-add + copy)
+        uint32_t *p = run + pos;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            if (planes[i] != 0) run[pos++] = planes[i];
+            if (planes[i] != 0) *p++ = planes[i];
         }
     }
 }

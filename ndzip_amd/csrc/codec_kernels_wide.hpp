@@ -223,12 +223,12 @@ struct coding<uint64_t> {
         const int q = t & 3;
         const uint32_t c = static_cast<uint32_t>(t) >> 2;
         if (q < 2) run32[2 * c + (q == 0 ? 1u : 0u)] = h.head_word;
-        uint32_t w = h.slot;
+        uint32_t *p = run32 + h.slot;  // (a running pointer: one address increment per kept plane)
 #pragma unroll
         for (int i = 0; i < planes_per_lane; ++i) {
             if ((h.head_bits >> (31 - i)) & 1u) {
-                run32[w] = planes[i];
-                w += 2;
+                *p = planes[i];
+                p += 2;
             }
         }
     }
