@@ -213,7 +213,9 @@ class hip_compressor {
                 _handle, in_device_data, data_size.dimensions(), data_size.begin(), out_device_stream, out_device_stream_length));
     }
 
-    // sticky device error word (look-back timeout); synchronises the stream
+    // Sticky device error word (look-back timeout); synchronises the stream.  compress() is asynchronous and cannot throw for a
+    // device-side failure: call this at the first host synchronisation after a compress() whose stream is kept (a timed-out launch
+    // also stores 0 to *out_device_stream_length, so a caller that only looks at the length still fails loudly).
     void check() { hip_detail::check(ndzip_hip_compressor_check(_handle)); }
     ndzip_hip_compressor *native_handle() { return _handle; }
 
