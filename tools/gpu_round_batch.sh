@@ -15,8 +15,8 @@ rocminfo | grep -E "gfx|Compute Unit" | head -4 > ${O}_rocminfo.txt
 (timeout 180 python __graft_entry__.py smoke 2>&1 | tail -3) >> ${O}_gputest.txt
 timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
 (timeout 900 bash tools/bench_configs.sh 2>&1) > ${O}_configs.txt
-timeout 900 bash tools/pmc.sh ${O}_rocprofv3_summary.txt
-timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_2d.txt --config 3
+TRAFFIC_KEY=float32-512x512x512 timeout 900 bash tools/pmc.sh ${O}_rocprofv3_summary.txt
+TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_2d.txt --config 3
 if [ -f ndzip_amd/_variants/plainloads.so ]; then (timeout 600 bash tools/ab.sh "main plainloads" 2>&1) > ${O}_ab_nt_loads.txt; fi
 for i in 1 2 3 4 5 6; do
   echo "== run $i" >> ${O}_two_process_stress.txt

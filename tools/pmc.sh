@@ -12,5 +12,10 @@ rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $P/pmc4 -o pmc
 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_STALL_sum --output-format csv -d $P/pmc5 -o pmc5 -- $B > $P/pmc5.log 2>&1
 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr --output-format csv -d $P/pmc6 -o pmc6 -- $B > $P/pmc6.log 2>&1
 cd $R
-python tools/prof_summary.py $P > $OUT 2>&1
+# TRAFFIC_KEY (e.g. float32-512x512x512) also merges the FETCH/WRITE bytes of this run into gpurun_out/traffic.json
+if [ -n "$TRAFFIC_KEY" ]; then
+  python tools/prof_summary.py $P --traffic "$TRAFFIC_KEY" gpurun_out/traffic.json "$OUT (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" > $OUT 2>&1
+else
+  python tools/prof_summary.py $P > $OUT 2>&1
+fi
 rm -rf $P
