@@ -186,3 +186,31 @@ def test_benchmark_tool_on_the_model(tmp_path):
         assert c[1] in ("float", "double") and int(c[2]) == dims and c[3] == "ndzip-hip" and c[4] == "1" and c[5] == "1"
         assert len(c[6].split(",")) >= 2 and len(c[7].split(",")) >= 2
         assert int(c[8]) == raw and int(c[9]) == comp
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/benchmark/plot_benchmark.py"), reason="the reference tree only exists in the authoring container")
+def test_reference_plot_script_reads_our_benchmark_rows(tmp_path):
+    """the rows ndzip-hip-benchmark prints are fed to the reference's own plot_benchmark.py UNCHANGED (run from where
+    it lies, headless); it must parse them and tabulate an `ndzip-hip` line for both value types."""
+    pytest.importorskip("matplotlib")
+    pytest.importorskip("tabulate")
+    from ndzip_amd.synth import synth_numpy
+    from tests.wavesim import build as simbuild
+
+    lib = simbuild.build()
+    exe = str(tmp_path / "ndzip-hip-benchmark-model")
+    src = os.path.join(os.path.dirname(build.__file__), "cli", "ndzip_hip_benchmark.cc")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, src, lib, "-Wl,-rpath," + os.path.dirname(lib)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = []
+    for name, dtype, shape in [("a.f32", np.float32, (64, 128)), ("b.f32", np.float32, (32, 32, 32)), ("c.f64", np.float64, (64, 64)), ("d.f64", np.float64, (8192,))]:
+        synth_numpy(shape, dtype, seed=3, noise_mask=0xFF).tofile(tmp_path / name)
+        lines.append(f"{name};{'float' if dtype == np.float32 else 'double'};{' '.join(str(x) for x in shape)}")
+    (tmp_path / "sets.csv").write_text("\n".join(lines) + "\n")
+    r = subprocess.run([exe, "-r", "3", "-t", "0", str(tmp_path / "sets.csv")], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    (tmp_path / "rows.csv").write_bytes(r.stdout)
+    p = subprocess.run([os.sys.executable, "/root/reference/src/benchmark/plot_benchmark.py", str(tmp_path / "rows.csv")], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, MPLBACKEND="Agg"), cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert p.stdout.count("ndzip-hip 1") >= 2 and "(float)" in p.stdout and "(double)" in p.stdout and "MB/s" in p.stdout
