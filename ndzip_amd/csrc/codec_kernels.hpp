@@ -134,10 +134,13 @@ struct __attribute__((packed, aligned(4))) unaligned8 {
     u32x2_t v;
 };
 // Array input is read exactly once per launch: the aligned path uses the read-once (nt) policy (gfx950_lds.hpp); build with
-// -DNDZIP_PLAIN_INPUT_LOADS to A/B against the default cache policy.
-template<bool Aligned>
+// -DNDZIP_PLAIN_INPUT_LOADS to A/B against the default cache policy.  Once = false: the caller reads only part of every cache
+// line and another workgroup the rest (the 64-byte rows of an unpaired 3D f32 hypercube), so the line should stay cacheable.
+template<bool Aligned, bool Once = true>
 NDZIP_DEV vec16 global_load16(const void *p) {
-    if constexpr (Aligned) {
+    if constexpr (Aligned && !Once) {
+        return *reinterpret_cast<const vec16 *>(p);
+    } else if constexpr (Aligned) {
 #ifdef NDZIP_PLAIN_INPUT_LOADS
         return *reinterpret_cast<const vec16 *>(p);
 #else
@@ -362,7 +365,8 @@ NDZIP_DEV void load_hypercube_regs(const typename profile<T, Dims>::word *__rest
     const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
     const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE);
 #pragma unroll
-    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned>(base + i * step);
+    constexpr bool whole_lines = !(Dims == 3 && sizeof(W) == 4);  // (3D f32 rows are 64 bytes: half a line each)
+    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned, whole_lines>(base + i * step);
 }
 
 // phase 0b: rotl1 and store to the padded LDS staging layout
