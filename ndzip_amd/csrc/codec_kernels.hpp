@@ -364,8 +364,8 @@ NDZIP_DEV void load_hypercube_regs(const typename profile<T, Dims>::word *__rest
     // crosses a hypercube row (VE divides the side length), so the same path serves unaligned rows.
     const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
     const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE);
-#pragma unroll
     constexpr bool whole_lines = !(Dims == 3 && sizeof(W) == 4);  // (3D f32 rows are 64 bytes: half a line each)
+#pragma unroll
     for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned, whole_lines>(base + i * step);
 }
 
