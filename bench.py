@@ -353,8 +353,12 @@ def main(argv=None):
 
     from ndzip_amd import hip
 
-    if args.lib:
-        hip.LIB_PATH = os.path.abspath(args.lib)
+    if args.lib:  # (a variant may be a build of an earlier commit that lacks the newest entry points: bind what it has)
+        import ctypes
+
+        import torch  # noqa: F401  (first, so the library binds to the HIP runtime torch loaded)
+
+        hip._lib = hip._bind(ctypes.CDLL(os.path.abspath(args.lib)), strict=False)
     import ndzip_amd
     from ndzip_amd.sharded import ShardedCodec, plan_shards
     from ndzip_amd.synth import synth_torch

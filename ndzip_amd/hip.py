@@ -104,8 +104,33 @@ def lib():
     return _lib
 
 
-def _bind(L):
+class _Tolerant:
+    """A/B tooling only (bench.py --lib with a build of an EARLIER commit): entry points that build does not have yet bind to
+    nothing instead of failing the load.  The package itself always binds strictly."""
+
+    def __init__(self, L):
+        object.__setattr__(self, "_L", L)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._L, name)
+        except AttributeError:
+            class _Missing:
+                argtypes = None
+                restype = None
+
+                def __call__(self, *a):
+                    raise NdzipHipError(ERR_RUNTIME, f"{name} is not exported by this build of the library")
+
+            m = _Missing()
+            object.__setattr__(self, name, m)
+            return m
+
+
+def _bind(L, strict: bool = True):
     """Declare the argument types of every entry point of include/ndzip_hip.h on a loaded library."""
+    if not strict:
+        L = _Tolerant(L)
     L.ndzip_hip_last_error.restype = C.c_char_p
     L.ndzip_hip_device_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
     L.ndzip_hip_compressed_length_bound.argtypes = [C.c_int, C.c_int, _U32P, C.POINTER(C.c_uint64)]

@@ -17,11 +17,15 @@ timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
 (timeout 900 bash tools/bench_configs.sh 2>&1) > ${O}_configs.txt
 TRAFFIC_KEY=float32-512x512x512 timeout 900 bash tools/pmc.sh ${O}_rocprofv3_summary.txt
 TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_2d.txt --config 3
-if [ -f ndzip_amd/_variants/plainloads.so ]; then (timeout 600 bash tools/ab.sh "main plainloads" 2>&1) > ${O}_ab_nt_loads.txt; fi
+# A/B of whatever variants were built on the CPU beforehand (tools/build_variant.sh, tools/build_history_variant.sh):
+#   plainloads = main without the nt input loads; dpp = before the ticket / window moves; r01 = the round-1 pipeline
+V="main"; for v in plainloads dpp r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
+(timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt
+(timeout 600 bash tools/ab.sh "$V" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
 for i in 1 2 3 4 5 6; do
   echo "== run $i" >> ${O}_two_process_stress.txt
   HSA_ENABLE_IPC_MODE_LEGACY=0 CHECK_EACH=0 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
       --master-port $((29510 + i)) tools/sharded_stress.py 40 >> ${O}_two_process_stress.txt 2>&1
   echo "exit $?" >> ${O}_two_process_stress.txt
 done
-tail -5 ${O}_gputest.txt; cat ${O}_bench_n1.json; cat ${O}_configs.txt; tail -14 ${O}_two_process_stress.txt
+tail -5 ${O}_gputest.txt; cat ${O}_bench_n1.json; cat ${O}_configs.txt; cat ${O}_ab_variants.txt; tail -14 ${O}_two_process_stress.txt
