@@ -177,7 +177,9 @@ struct mapped_input final : input {  // io.cc:118-176
         }
         size = static_cast<size_t>(st.st_size);
         if (size) {
-            map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            // (a private, WRITABLE view although it is never written: the HIP runtime may pin the pages it copies from, and
+            // pinning a read-only mapping can be refused)
+            map = mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_POPULATE, fd, 0);
             if (map == MAP_FAILED) {
                 close(fd);
                 throw std::runtime_error("mmap: " + name + ": " + strerror(errno));
