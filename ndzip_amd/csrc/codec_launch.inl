@@ -444,7 +444,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         // it there: ISA + the ~3 k cycles of its "top of the iteration" phase timer).  Issued here it is in flight until the
         // resolve, most of an iteration later.
         lookback_windows window{};
+#ifndef NDZIP_EXP_WINDOW_BEHIND_PUBLISH
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
+#endif
         NDZIP_PHASE(0)  // wait prefetch + stage + window issue
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
         const uint32_t next_tile = have_cur ? tile_of_ticket(misc[NW + 1], cls, num_classes) : tile;
@@ -484,6 +486,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             chunk_excl = ((wave & 1) ? misc[2 * grp] : 0u) + incl - count;
             if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
+#ifdef NDZIP_EXP_WINDOW_BEHIND_PUBLISH  // experiment: the window a third of an iteration later, still ahead of the late prefetch
+        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
+#endif
         NDZIP_PHASE(9)  // aggregate + publish
         // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
         // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
@@ -504,11 +509,13 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         }
         NDZIP_PHASE(3)  // plane writes (prev)
         // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
+#ifndef NDZIP_EXP_TRANSPOSE_BEHIND_COPYOUT
         if (have_cur) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) planes[j] = r[j];
             transpose32(planes);
         }
+#endif
         NDZIP_PHASE(5)  // transposes
         __builtin_amdgcn_sched_barrier(0);
         // The previous tile's prefix, as the LAST thing wavefront 0 does before B3: its predecessors (which may lag by
@@ -541,6 +548,13 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             // the last tile ends the body (store_stream_length, cuda_codec.inl:507-511)
             if (tid == 0 && prev_tile == ntiles - 1) store_stream_length(out_len, len_extra + prefix + prev_aggregate);
         }
+#ifdef NDZIP_EXP_TRANSPOSE_BEHIND_COPYOUT  // experiment: the transposes cover the copy-out's store acknowledgements (resolve earlier)
+        if (have_cur) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) planes[j] = r[j];
+            transpose32(planes);
+        }
+#endif
         if (draw) misc[NW + 1] = ticket_after_next;
         NDZIP_PHASE(4)  // B3 + ticket + copy-out (prev)
         __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them; next ticket in LDS

@@ -19,7 +19,8 @@ TRAFFIC_KEY=float32-512x512x512 timeout 900 bash tools/pmc.sh ${O}_rocprofv3_sum
 TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_2d.txt --config 3
 # A/B of whatever variants were built on the CPU beforehand (tools/build_variant.sh, tools/build_history_variant.sh):
 #   plainloads = main without the nt input loads; dpp = before the ticket / window moves; r01 = the round-1 pipeline
-V="main"; for v in plainloads dpp r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
+#   winpub = look-back window issued behind the aggregate publish; trlate = transposes behind the copy-out (f32 only)
+V="main"; for v in plainloads winpub trlate dpp r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
 (timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt
 (timeout 600 bash tools/ab.sh "$V" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
 for i in 1 2 3 4 5 6; do
