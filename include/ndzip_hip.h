@@ -230,7 +230,9 @@ NDZIP_HIP_API int ndzip_hip_chunked_decompress(int dtype, int dims, const uint64
  *        1 encode 4096 residual words -> encoded run in `d_out` (4096 + 4096/B words capacity), *d_out_len words
  *        2 decode an encoded run -> 4096 residual words
  *        3 inverse transform of 4096 residual words -> hypercube `hc` of the device array `d_out`
- *        4 / 5 32x32 bit transposes of `n` blocks of 32 uint32 (v_perm network / shift-mask network) */
+ *        4 / 5 32x32 bit transposes of `n` blocks of 32 uint32 (v_perm network / shift-mask network)
+ *        6 the wave64 scan and sum (DPP): `n` uint32 (a multiple of 64) -> per wavefront the inclusive prefix sums, then
+ *          n / 64 wave totals behind them (`d_out` holds n + n / 64 words) */
 NDZIP_HIP_API int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in,
         void *d_out, uint32_t *d_out_len, uint32_t n, void *hip_stream);
 

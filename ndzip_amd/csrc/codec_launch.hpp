@@ -67,6 +67,8 @@ enum debug_stage : int {
     debug_inverse_transform = 3,  // in: 4096 residual words          -> out: array (hypercube hc of geometry)
     debug_transpose32 = 4,        // in: n*32 uint32                  -> out: n*32 uint32 (v_perm network)
     debug_transpose32_generic = 5,
+    debug_wave_scan = 6,          // in: n uint32 (n a multiple of 64)   -> out: per wavefront of 64, the inclusive prefix sums;
+                                  //                                         out[n + w] = the wave sum of wavefront w
 };
 
 template<typename T>

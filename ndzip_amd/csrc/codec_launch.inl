@@ -912,6 +912,16 @@ __global__ void debug_transpose_kernel(const uint32_t *in, uint32_t *out, uint32
     for (int j = 0; j < 32; ++j) out[i * 32 + j] = x[j];
 }
 
+// the DPP wave scan and wave sum on their own (one wavefront per 64 inputs)
+__global__ void debug_wave_scan_kernel(const uint32_t *in, uint32_t *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // (the grid covers n exactly: every lane of every wavefront is live)
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const uint32_t v = in[i];
+    out[i] = wave_inclusive_scan(v, lane);
+    const uint32_t total = wave_sum(v);
+    if (lane == 0) out[n + i / 64] = total;
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------------------
 
 // Experiment knobs (tools/ablate.sh, tools/ab.sh) exist only in builds with -DNDZIP_EXP_KNOBS; the production library reads
@@ -1087,6 +1097,12 @@ hipError_t launch_decompress<T_>(int dims, const decompress_args &a) {
 template<>
 hipError_t launch_debug_stage<T_>(int stage, int dims, const grid_geom &gg, uint32_t hc, const void *in, void *out,
         uint32_t *out_len, uint32_t n, bool aligned, hipStream_t stream) {
+    if (stage == debug_wave_scan) {
+        if (n == 0 || n % 64 != 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(debug_wave_scan_kernel, dim3(n / 64), dim3(64), 0, stream, static_cast<const uint32_t *>(in),
+                static_cast<uint32_t *>(out), n);
+        return hipGetLastError();
+    }
     if (stage == debug_transpose32 || stage == debug_transpose32_generic) {
         if (n == 0) return hipSuccess;
         hipLaunchKernelGGL(debug_transpose_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, static_cast<const uint32_t *>(in),

@@ -177,3 +177,25 @@ def test_forward_then_inverse_is_identity(hiplib, cuda_device, profile):
     hip.debug_stage(INV, dtype, dims, shape, 0, d_res, d_back)
     torch.cuda.synchronize()
     assert np.array_equal(_np(d_back, wdt), data.reshape(-1).view(wdt))
+
+
+def test_wave_scan_and_sum(hiplib, cuda_device):
+    """The DPP wave scan (row_shr 1/2/4/8 + row_bcast:15/31) and the wave sum (its last lane by v_readlane) on their own, against
+    numpy: uint32 wraparound included."""
+    import torch
+
+    from ndzip_amd import hip
+
+    rng = np.random.default_rng(4)
+    n = 64 * 9
+    x = rng.integers(0, 2**32, size=n, dtype=np.uint32)
+    x[:64] = 1
+    x[64:128] = 0xFFFFFFFF
+    x[128:192] = np.arange(64, dtype=np.uint32)
+    d_out = torch.zeros(n + n // 64, dtype=torch.int32, device=cuda_device)
+    hip.debug_stage(6, np.float32, 1, None, 0, _t(x, cuda_device), d_out, None, n)
+    torch.cuda.synchronize()
+    got = _np(d_out, np.uint32)
+    want = np.concatenate([np.cumsum(x.reshape(-1, 64).astype(np.uint64), axis=1).astype(np.uint32).reshape(-1),
+                           x.reshape(-1, 64).astype(np.uint64).sum(axis=1).astype(np.uint32)])
+    assert np.array_equal(got, want)
