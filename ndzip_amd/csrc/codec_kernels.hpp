@@ -636,11 +636,12 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
             uint32_t pos = base;
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                const uint32_t bit = (head >> (31 - i)) & 1u;
-                const uint32_t w = in32[pos];
-                r[i] = w & (0u - bit);
-                pos += bit;
+                r[i] = in32[pos];
+                pos += (head >> (31 - i)) & 1u;
             }
+            lds_reads_issued_before_use(r);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) r[i] &= static_cast<uint32_t>(static_cast<int32_t>(head << i) >> 31);
         }
         if constexpr (ComplementInPlaneDomain) {
 #pragma unroll
@@ -657,19 +658,31 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
         if (lane == 63) xchg[wave] = incl;
         __syncthreads();
         const uint32_t base = P::head_words + (wave ? xchg[0] : 0u) + incl - cnt;
-        const uint32_t n_hi = static_cast<uint32_t>(__builtin_popcount(head_hi));
+        // walk the chunk's kept planes from the LAST one back to the first: the byte pointer steps down one 64-bit plane per set
+        // head bit (pointer += 8 * mask with mask = 0 / -1 from one v_bfe_i32), the word under it is read speculatively (inside
+        // the run, or the 8 bytes behind it that the staging region holds) and kept iff the bit is set -- three VALU
+        // instructions per plane half instead of the mask / popcount / address / select of an indexed gather
         uint32_t hi[32], lo[32];
+        const char *p = cube + 8 * (base + cnt) + 4 * half;
+        int32_t kept_hi[32], kept_lo[32];  // 0 / -1 per plane (the kernel's occupancy is bound by LDS, not by these registers)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const uint32_t above = i == 0 ? 0u : (head_hi & ~(0xffffffffu >> i));
-            const uint32_t w = in32[2 * (base + static_cast<uint32_t>(__builtin_popcount(above))) + half];
-            hi[i] = ((head_hi >> (31 - i)) & 1u) ? w : 0u;
+        for (int i = 31; i >= 0; --i) {
+            kept_lo[i] = opaque_vgpr(static_cast<int32_t>(head_lo << i) >> 31);
+            p += 8 * kept_lo[i];
+            lo[i] = *reinterpret_cast<const uint32_t *>(p);
         }
 #pragma unroll
+        for (int i = 31; i >= 0; --i) {
+            kept_hi[i] = opaque_vgpr(static_cast<int32_t>(head_hi << i) >> 31);
+            p += 8 * kept_hi[i];
+            hi[i] = *reinterpret_cast<const uint32_t *>(p);
+        }
+        lds_reads_issued_before_use(lo);
+        lds_reads_issued_before_use(hi);
+#pragma unroll
         for (int i = 0; i < 32; ++i) {
-            const uint32_t above = i == 0 ? 0u : (head_lo & ~(0xffffffffu >> i));
-            const uint32_t w = in32[2 * (base + n_hi + static_cast<uint32_t>(__builtin_popcount(above))) + half];
-            lo[i] = ((head_lo >> (31 - i)) & 1u) ? w : 0u;
+            lo[i] &= static_cast<uint32_t>(kept_lo[i]);
+            hi[i] &= static_cast<uint32_t>(kept_hi[i]);
         }
         if constexpr (ComplementInPlaneDomain) {
             // hi[0] is this lane's half of the sign plane; it covers the same 32 values as all its other plane halves

@@ -40,6 +40,26 @@ NDZIP_DEV vec16 lds_read16(const char *p) {
     return v;
 }
 
+// Scheduling fence for a batch of 32 word reads from LDS: every LDS access above it is issued before any of `w` is used
+// below it.  Left alone, hipcc interleaves a dependent-address gather with the uses of its results (ds_read_b32 ;
+// s_waitcnt lgkmcnt(0) ; v_and ; next address ; ds_read_b32 ...), one exposed LDS round trip per word; with the fence the
+// address chain and the reads go out back to back and the wavefront waits once.  (Two statements: an asm takes at most 30
+// operands.  The "memory" clobber is what keeps the reads above the first one.)
+NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&w)[32]) {
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]),
+            "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15])::"memory");
+    asm volatile("" : "+v"(w[16]), "+v"(w[17]), "+v"(w[18]), "+v"(w[19]), "+v"(w[20]), "+v"(w[21]), "+v"(w[22]), "+v"(w[23]),
+            "+v"(w[24]), "+v"(w[25]), "+v"(w[26]), "+v"(w[27]), "+v"(w[28]), "+v"(w[29]), "+v"(w[30]), "+v"(w[31])::"memory");
+}
+
+// The value, as far as the optimiser is concerned, from nowhere: stops hipcc from rewriting `p + 8 * (x << i >> 31)` into
+// bfe(4 bits) / and -8 / add (three instructions) where v_bfe_i32 + v_lshl_add_u32 (two) do, and lets the 0 / -1 mask be
+// reused for the select afterwards.
+NDZIP_DEV int32_t opaque_vgpr(int32_t x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
 // All vector-memory operations this wavefront has issued (loads, stores, atomics -- gfx9 counts them in one counter) have
 // completed.  Between write-through / atomic accesses this is all the ordering an agent-scope hand-off needs.
 NDZIP_DEV void wait_for_own_memory_operations() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -26,6 +26,10 @@ NDZIP_DEV vec16 lds_read16(const char *p) {
     return v;
 }
 
+NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction scheduling only)
+
+NDZIP_DEV int32_t opaque_vgpr(int32_t x) { return x; }
+
 NDZIP_DEV void wait_for_own_memory_operations() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 NDZIP_DEV vec16 global_load16_once(const void *p) {
