@@ -770,10 +770,13 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
         {
             constexpr int VE = 16 / sizeof(W);
             constexpr int NV = hc_size / VE / threads_per_hc;
+            vec16 all[NV];  // (every read issued before the first store: one LDS round trip instead of NV)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) all[i] = lds_read16(cube + L::off(static_cast<uint32_t>(i * threads_per_hc + t) * VE));
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * VE;
-                vec16 v = lds_read16(cube + L::off(k));
+                vec16 v = all[i];
                 if constexpr (sizeof(W) == 4) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v.w[j] = rotr1(v.w[j]);
@@ -812,26 +815,31 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
         W *dst = out + origin + static_cast<uint64_t>(y) * gg.stride[1] + 2 * xp;
         const char *src = cube + L::off(y * 16 + 2 * xp);
         constexpr uint32_t plane_bytes = L::off(256);
+        if constexpr (sizeof(W) == 4) {
 #pragma unroll
-        for (uint32_t z = 0; z < 16; ++z, dst += gg.stride[0]) {
-            const char *p = src + z * plane_bytes;
-            W *const gp = dst;
-            if constexpr (sizeof(W) == 4) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(p);
+            for (uint32_t z = 0; z < 16; ++z, dst += gg.stride[0]) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(src + z * plane_bytes);
                 acc0 += v.x;
                 acc1 += v.y;
-                global_store8<Aligned>(gp, rotr1(acc0), rotr1(acc1));
-            } else {
-                const vec16 v = lds_read16(p);
-                acc0 += static_cast<uint64_t>(v.w[0]) | (static_cast<uint64_t>(v.w[1]) << 32);
-                acc1 += static_cast<uint64_t>(v.w[2]) | (static_cast<uint64_t>(v.w[3]) << 32);
+                global_store8<Aligned>(dst, rotr1(acc0), rotr1(acc1));
+            }
+        } else {
+            // all 16 reads first: written as one loop, hipcc serialises "ds_read_b128, s_waitcnt lgkmcnt(0), add, store" 16 times
+            // (the f64 decoder runs at 2 waves/SIMD -- there is little else to cover an LDS round trip with)
+            vec16 v[16];
+#pragma unroll
+            for (uint32_t z = 0; z < 16; ++z) v[z] = lds_read16(src + z * plane_bytes);
+#pragma unroll
+            for (uint32_t z = 0; z < 16; ++z, dst += gg.stride[0]) {
+                acc0 += static_cast<uint64_t>(v[z].w[0]) | (static_cast<uint64_t>(v[z].w[1]) << 32);
+                acc1 += static_cast<uint64_t>(v[z].w[2]) | (static_cast<uint64_t>(v[z].w[3]) << 32);
                 const uint64_t o0 = rotr1(acc0), o1 = rotr1(acc1);
                 vec16 w;
                 w.w[0] = static_cast<uint32_t>(o0);
                 w.w[1] = static_cast<uint32_t>(o0 >> 32);
                 w.w[2] = static_cast<uint32_t>(o1);
                 w.w[3] = static_cast<uint32_t>(o1 >> 32);
-                global_store16<Aligned>(gp, w);
+                global_store16<Aligned>(dst, w);
             }
         }
     }
