@@ -43,7 +43,6 @@ FULL = [("cfg2 3D f32 512^3", (512, 512, 512), np.float32), ("cfg3 2D f64 8192^2
         ("cfg5 rank slab 3D f64 128x1024x1024", (128, 1024, 1024), np.float64)]
 
 
-@pytest.mark.hardware_only
 @pytest.mark.parametrize("name,shape,dtype", FULL, ids=[f[0] for f in FULL])
 def test_full_size_configs(hiplib, cuda_device, name, shape, dtype):
     """BASELINE.json configs at full size: stream identical to the (multi-threaded) oracle, header strictly increasing and
