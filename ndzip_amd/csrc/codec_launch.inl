@@ -777,7 +777,7 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
 #pragma unroll
         for (int i = 0; i < vec_per_thread; ++i) {
             const uint32_t j = static_cast<uint32_t>(i * threads_per_hc + t);
-            if (j < nvec) v[i] = global_load16<true>(src16 + j);  // (the stream is read once too)
+            if (j < nvec) v[i] = global_load16_block(src16 + j);  // (read once; the end blocks may hold foreign words)
         }
 #pragma unroll
         for (int i = 0; i < vec_per_thread; ++i) {

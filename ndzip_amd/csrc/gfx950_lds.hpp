@@ -78,4 +78,11 @@ NDZIP_DEV vec16 global_load16_once(const void *p) {
     return v;
 }
 
+// The 16-byte aligned block around words of a stream, read once.  The decoder fetches an encoded run as whole aligned blocks,
+// so a run's first and last block can hold up to three words of the neighbouring runs -- or, at the two ends of a stream, of
+// nobody.  An aligned 16-byte load cannot straddle a page: the access is safe whenever one of its words is, and the surplus
+// words are never looked at.  (The functional model checks exactly this contract under AddressSanitizer: at least one word of
+// the block inside the caller's buffer, junk substituted for the others.)
+NDZIP_DEV vec16 global_load16_block(const void *p) { return global_load16_once(p); }
+
 }  // namespace ndzip_hip

@@ -1,0 +1,55 @@
+"""Memory safety of the kernels, on the functional model built with AddressSanitizer (test infrastructure only): "device" buffers
+are exactly as large as asked for (numpy / posix_memalign allocations with red zones behind them), dynamic LDS ends where the launch
+said it ends (the rest of the 160 KiB is poisoned), and every byte outside traps with the kernel's source line.  The one access
+pattern that is allowed to look beyond a buffer is the decoder's aligned 16-byte block load (`global_load16_block`,
+ndzip_amd/csrc/gfx950_lds.hpp): at least one word inside, the others replaced by junk here -- so these runs also prove that the
+surplus words never reach the output.
+
+The sanitised library needs the ASan runtime in the process before Python starts, hence the subprocess with LD_PRELOAD.
+`tools/asan_rehearsal.sh` runs the whole rehearsed `-m gpu` suite (full-size BASELINE configs included) the same way."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from tests.wavesim import build as simbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def asan_env():
+    runtime = simbuild.asan_runtime()
+    if not os.path.isfile(runtime):
+        pytest.skip("the compiler has no shared AddressSanitizer runtime")
+    simbuild.build(variant="asan", extra_flags=simbuild.ASAN_FLAGS)
+    env = dict(os.environ)
+    env.update(LD_PRELOAD=runtime, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0", WAVESIM_VARIANT="asan")
+    return env
+
+
+def test_kernels_are_clean_under_address_sanitizer():
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_wavesim_codec.py", "tests/test_wavesim_stages.py", "-q", "-x", "-p",
+                        "no:cacheprovider"], cwd=ROOT, env=asan_env(), capture_output=True, text=True, timeout=1500)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, r.stdout[-2000:] + r.stderr[-4000:]
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 200, tail
+
+
+def test_the_sanitised_model_does_trap():
+    """The positive control: a stream buffer a quarter of the bound makes the compress kernel's copy-out run off its end."""
+    code = ("import numpy as np\n"
+            "from tests.wavesim import sim\n"
+            "from ndzip_amd import hip, synth\n"
+            "x = synth.synth_numpy((64, 64, 64), np.float32)\n"
+            "with sim.active(2, 2):\n"
+            "    out = np.zeros(hip.compressed_length_bound(x.dtype, x.shape) // 4, dtype=np.uint32)\n"
+            "    length = np.zeros(1, dtype=np.uint32)\n"
+            "    comp = hip.make_hip_compressor(x.dtype, hip.CompressorRequirements(x.shape))\n"
+            "    comp.compress(x.ctypes.data, x.shape, out.ctypes.data, length.ctypes.data)\n"
+            "print('no trap')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=asan_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "heap-buffer-overflow" in r.stderr and "copy_out" in r.stderr, r.stdout[-500:] + r.stderr[-3000:]
+    assert "no trap" not in r.stdout

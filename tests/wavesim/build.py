@@ -30,11 +30,20 @@ def _sources():
     return files
 
 
-def build(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> str:
-    """variant / defines: a second library built with extra -D flags (e.g. a tiny look-back spin limit), suffixed _<variant>."""
+ASAN_FLAGS = ("-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g1")
+
+
+def asan_runtime() -> str:
+    """The shared AddressSanitizer runtime of CXX: what a Python process has to LD_PRELOAD to load the `asan` variant."""
+    return subprocess.run([CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True).stdout.strip()
+
+
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=(), extra_flags=()) -> str:
+    """variant / defines / extra_flags: a second library built with extra -D or compiler flags (e.g. a tiny look-back spin
+    limit, or ASAN_FLAGS for the memory-safety run of tests/test_wavesim_asan.py), suffixed _<variant>."""
     OUT = os.path.join(HERE, f"libndzip_hip_wavesim{'_' + variant if variant else ''}.so")
     BUILD = os.path.join(HERE, "_build", variant or "default")
-    FLAGS = list(globals()["FLAGS"]) + [f"-D{d}" for d in defines]
+    FLAGS = list(globals()["FLAGS"]) + [f"-D{d}" for d in defines] + list(extra_flags)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in _sources()):
         return OUT
     # mirror the product tree so that its relative includes resolve, with the one substituted header
@@ -62,7 +71,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
     jobs.append((os.path.join(HERE, "wavesim.cc"), os.path.join(BUILD, "wavesim.o")))
     with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(compile_one, jobs))
-    cmd = [CXX, "-shared", "-fPIC", "-pthread", "-o", OUT, *objs]
+    cmd = [CXX, "-shared", "-fPIC", "-pthread", *[f for f in extra_flags if f.startswith(("-fsanitize", "-shared-lib"))], "-o", OUT, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"wavesim link failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

@@ -42,4 +42,39 @@ NDZIP_DEV vec16 global_load16_once(const void *p) {
     return v;
 }
 
+// The decoder's block load: legal when at least one of the four words lies inside the caller's buffer.  An AddressSanitizer
+// build of the model checks that, and hands back junk for the words that are outside -- they must not influence the result.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define WAVESIM_LDS_ASAN 1
+extern "C" int __asan_address_is_poisoned(void const volatile *addr);
+#endif
+#endif
+NDZIP_DEV vec16 global_load16_block(const void *p) {
+    if (reinterpret_cast<uintptr_t>(p) % 16 != 0) {
+        fprintf(stderr, "wavesim: global_load16_block at a misaligned address\n");
+        abort();
+    }
+    vec16 v;
+#ifdef WAVESIM_LDS_ASAN
+    const char *c = static_cast<const char *>(p);
+    int inside = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (__asan_address_is_poisoned(c + 4 * i) || __asan_address_is_poisoned(c + 4 * i + 3)) {
+            v.w[i] = 0xdeadbeefu;
+        } else {
+            std::memcpy(&v.w[i], c + 4 * i, 4);
+            ++inside;
+        }
+    }
+    if (inside == 0) {
+        fprintf(stderr, "wavesim: global_load16_block of a block that is entirely outside the buffer\n");
+        abort();
+    }
+#else
+    std::memcpy(&v, p, sizeof v);
+#endif
+    return v;
+}
+
 }  // namespace ndzip_hip

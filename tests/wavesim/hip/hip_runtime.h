@@ -57,7 +57,10 @@ void sleep_hint();                               // s_sleep: lets other workgrou
 
 struct launch_cfg {
     unsigned grid, block;
+    size_t lds_bytes;          // dynamic LDS the launch asked for
+    char *(*lds_base)();       // the calling translation unit's LDS array of the CURRENT thread (it is thread_local)
 };
+constexpr size_t lds_capacity = 160 * 1024;
 // runs fn(arg) once per work-item of grid x block; workgroups are co-resident up to WAVESIM_MAX_RESIDENT (default 32)
 void run_grid(launch_cfg cfg, void (*fn)(void *), void *arg);
 
@@ -77,7 +80,7 @@ static const wavesim_idx gridDim{{&wavesim::lane_grid_dim}};
 // ---- LDS: `extern __shared__ char smem[]` inside a kernel resolves to this per-workgroup-thread array ------------------
 namespace ndzip_hip {
 namespace {
-alignas(16) thread_local char smem[160 * 1024];
+alignas(16) thread_local char smem[wavesim::lds_capacity];
 }
 }  // namespace ndzip_hip
 
@@ -210,9 +213,13 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     snprintf(p->gcnArchName, sizeof p->gcnArchName, "gfx950-wavesim");
     return hipSuccess;
 }
+// Device memory: exactly the bytes asked for (an AddressSanitizer build of the model then traps the first byte beyond), and
+// filled with junk -- hipMalloc does not hand out zeroed memory and the kernels must not count on it.
 inline hipError_t hipMalloc(void **p, size_t bytes) {
-    *p = aligned_alloc(256, (bytes + 255) / 256 * 256);
-    return *p ? hipSuccess : hipErrorOutOfMemory;
+    *p = nullptr;
+    if (posix_memalign(p, 256, bytes ? bytes : 1) != 0) return hipErrorOutOfMemory;
+    memset(*p, 0xCD, bytes);
+    return hipSuccess;
 }
 inline hipError_t hipFree(void *p) {
     free(p);
@@ -267,14 +274,14 @@ inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, s
 #include <utility>
 
 template<typename... Params, typename... Args>
-inline void wavesim_launch(void (*kernel)(Params...), dim3 grid, dim3 block, Args &&...args) {
+inline void wavesim_launch(void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds_bytes, Args &&...args) {
     std::tuple<std::decay_t<Params>...> bound{static_cast<std::decay_t<Params>>(std::forward<Args>(args))...};
     struct thunk_t {
         void (*kernel)(Params...);
         std::tuple<std::decay_t<Params>...> *bound;
     } thunk{kernel, &bound};
     wavesim::run_grid(
-            wavesim::launch_cfg{grid.x, block.x},
+            wavesim::launch_cfg{grid.x, block.x, lds_bytes, +[]() -> char * { return ndzip_hip::smem; }},
             [](void *p) {
                 auto *t = static_cast<thunk_t *>(p);
                 std::apply(t->kernel, *t->bound);
@@ -282,4 +289,4 @@ inline void wavesim_launch(void (*kernel)(Params...), dim3 grid, dim3 block, Arg
             &thunk);
 }
 #define hipLaunchKernelGGL(kernel, grid, block, smem_bytes, stream, ...) \
-    ((void) (smem_bytes), (void) (stream), wavesim_launch(kernel, grid, block, __VA_ARGS__))
+    ((void) (stream), wavesim_launch(kernel, grid, block, static_cast<size_t>(smem_bytes), __VA_ARGS__))

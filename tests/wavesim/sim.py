@@ -16,8 +16,13 @@ _sim = {}
 
 
 def load(variant: str = "", defines=()):
+    """WAVESIM_VARIANT=asan in the environment (with the AddressSanitizer runtime LD_PRELOADed, tests/test_wavesim_asan.py)
+    makes the default library the sanitised one."""
+    if not variant and os.environ.get("WAVESIM_VARIANT") == "asan":
+        variant = "asan"
     if variant not in _sim:
-        _sim[variant] = hip._bind(C.CDLL(simbuild.build(variant=variant, defines=defines)))
+        flags = simbuild.ASAN_FLAGS if variant == "asan" else ()
+        _sim[variant] = hip._bind(C.CDLL(simbuild.build(variant=variant, defines=defines, extra_flags=flags)))
     return _sim[variant]
 
 

@@ -155,8 +155,36 @@ struct thread_stacks {
     }
 };
 
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define WAVESIM_ASAN 1
+extern "C" void __asan_poison_memory_region(void const volatile *, size_t);
+extern "C" void __asan_unpoison_memory_region(void const volatile *, size_t);
+#endif
+#endif
+
+// LDS as a workgroup finds it: whatever the previous one left (here: junk -- a kernel that counts on zeroed LDS is wrong on
+// hardware), and only as much as the launch asked for (an AddressSanitizer build traps the first byte beyond).
+struct lds_guard {
+    char *base;
+    size_t used;
+    lds_guard(const launch_cfg &cfg) : base(cfg.lds_base()), used(cfg.lds_bytes) {
+        if (used > lds_capacity) die("launch asks for more LDS than a CU has");
+        memset(base, 0xA5, lds_capacity);
+#ifdef WAVESIM_ASAN
+        __asan_poison_memory_region(base + used, lds_capacity - used);
+#endif
+    }
+    ~lds_guard() {
+#ifdef WAVESIM_ASAN
+        __asan_unpoison_memory_region(base + used, lds_capacity - used);
+#endif
+    }
+};
+
 void run_workgroup(unsigned block_idx, launch_cfg cfg, void (*fn)(void *), void *arg, thread_stacks &stacks) {
     if (cfg.block == 0 || cfg.block > 1024) die("block size must be 1..1024");
+    lds_guard lds(cfg);
     wg_state wg;
     wg.block_idx = block_idx;
     wg.block_dim = cfg.block;
