@@ -120,7 +120,10 @@ NDZIP_HIP_API int ndzip_hip_compressor_destroy(ndzip_hip_compressor *c);
 NDZIP_HIP_API int ndzip_hip_decompressor_create(int dtype, int dims, void *hip_stream, ndzip_hip_decompressor **out);
 
 /* cuda_decompressor<T>::decompress(in_device_stream, out_device_data, data_size)
- * (include/ndzip/cuda.hh:25-34, src/ndzip/cuda_codec.inl:628-652).  Asynchronous on the handle's stream. */
+ * (include/ndzip/cuda.hh:25-34, src/ndzip/cuda_codec.inl:628-652).  Asynchronous on the handle's stream.
+ * Encoded runs are fetched as 16-byte aligned blocks: the kernel may LOAD (never use, never store) up to 12 bytes in front
+ * of the first and behind the last word of the stream's bodies, inside the aligned 16-byte block that holds that word --
+ * harmless for any device allocation (such a block cannot straddle a page). */
 NDZIP_HIP_API int ndzip_hip_decompressor_decompress(
         ndzip_hip_decompressor *d, const void *d_stream, void *d_out, int dims, const uint32_t *extent);
 
