@@ -38,7 +38,12 @@ def asan_runtime() -> str:
     return subprocess.run([CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True).stdout.strip()
 
 
-def build(force: bool = False, verbose: bool = False, variant: str = "", defines=(), extra_flags=()) -> str:
+# the LDS access profile (wavesim.cc): every load / store of the product's translation units calls a hook; the scheduler itself is
+# compiled without (its hooks must not call themselves)
+LDSPROF_FLAGS = ("-fsanitize-coverage=edge,trace-loads,trace-stores", "-g1")  # ("edge": without a coverage type clang instruments nothing)
+
+
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=(), extra_flags=(), kernel_flags=()) -> str:
     """variant / defines / extra_flags: a second library built with extra -D or compiler flags (e.g. a tiny look-back spin
     limit, or ASAN_FLAGS for the memory-safety run of tests/test_wavesim_asan.py), suffixed _<variant>."""
     OUT = os.path.join(HERE, f"libndzip_hip_wavesim{'_' + variant if variant else ''}.so")
@@ -59,7 +64,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
 
     def compile_one(job):
         source, obj = job
-        cmd = [CXX, *FLAGS, "-x", "c++", "-I", HERE, "-c", source, "-o", obj]
+        cmd = [CXX, *FLAGS, *(kernel_flags if source.endswith(".hip") else ()), "-x", "c++", "-I", HERE, "-c", source, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -12,18 +12,31 @@ namespace ndzip_hip {
 
 #define NDZIP_DEV __device__ __forceinline__
 
+#ifdef WAVESIM_LDSPROF
+// the access-profile build (tools/lds_profile.py): 16 bytes travel as ONE 16-byte access (volatile: the host optimiser may not
+// split it), so that the load / store hooks see a ds_read_b128 / ds_write_b128 as such
+struct alignas(16) vec16 {
+    uint32_t w[4];
+    vec16() = default;
+    vec16(const vec16 &o) { *this = o; }
+    vec16 &operator=(const vec16 &o) {
+        typedef uint32_t __attribute__((ext_vector_type(4), may_alias)) u32x4;
+        *reinterpret_cast<volatile u32x4 *>(w) = *reinterpret_cast<const volatile u32x4 *>(o.w);
+        return *this;
+    }
+};
+#else
 struct alignas(16) vec16 {
     uint32_t w[4];
 };
+#endif
 
 NDZIP_DEV vec16 lds_read16(const char *p) {
     if (reinterpret_cast<uintptr_t>(p) % 16 != 0) {  // a misaligned ds_read_b128 is a kernel bug (and 16x slower on gfx950)
         fprintf(stderr, "wavesim: lds_read16 at a misaligned address\n");
         abort();
     }
-    vec16 v;
-    std::memcpy(&v, p, sizeof v);
-    return v;
+    return *reinterpret_cast<const vec16 *>(p);
 }
 
 NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction scheduling only)
@@ -37,9 +50,7 @@ NDZIP_DEV vec16 global_load16_once(const void *p) {
         fprintf(stderr, "wavesim: global_load16_once at a misaligned address\n");
         abort();
     }
-    vec16 v;
-    std::memcpy(&v, p, sizeof v);
-    return v;
+    return *reinterpret_cast<const vec16 *>(p);
 }
 
 // The decoder's block load: legal when at least one of the four words lies inside the caller's buffer.  An AddressSanitizer
@@ -72,7 +83,7 @@ NDZIP_DEV vec16 global_load16_block(const void *p) {
         abort();
     }
 #else
-    std::memcpy(&v, p, sizeof v);
+    v = *reinterpret_cast<const vec16 *>(p);
 #endif
     return v;
 }

@@ -162,9 +162,25 @@ inline T atomicOr(T *p, T v) {
     return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST);
 }
 
+#ifdef WAVESIM_LDSPROF
+// the access-profile build: an 8-byte value travels as ONE 8-byte access (volatile: the host optimiser may not split it into the
+// two dwords the fields are), so that the hooks see the width the GPU instruction has
+struct alignas(8) uint2 {
+    uint32_t x, y;
+    uint2() = default;
+    uint2(uint32_t a, uint32_t b) : x(a), y(b) {}
+    uint2(const uint2 &o) { *this = o; }
+    uint2 &operator=(const uint2 &o) {
+        typedef uint64_t __attribute__((may_alias)) u64;
+        *reinterpret_cast<volatile u64 *>(this) = *reinterpret_cast<const volatile u64 *>(&o);
+        return *this;
+    }
+};
+#else
 struct uint2 {
     uint32_t x, y;
 };
+#endif
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 
 // ---- host runtime: "device memory" is the heap, streams are synchronous -------------------------------------------------

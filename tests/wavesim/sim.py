@@ -22,7 +22,10 @@ def load(variant: str = "", defines=()):
         variant = "asan"
     if variant not in _sim:
         flags = simbuild.ASAN_FLAGS if variant == "asan" else ()
-        _sim[variant] = hip._bind(C.CDLL(simbuild.build(variant=variant, defines=defines, extra_flags=flags)))
+        kflags = simbuild.LDSPROF_FLAGS if variant == "ldsprof" else ()
+        if variant == "ldsprof":
+            defines = tuple(defines) + ("WAVESIM_LDSPROF",)
+        _sim[variant] = hip._bind(C.CDLL(simbuild.build(variant=variant, defines=defines, extra_flags=flags, kernel_flags=kflags)))
     return _sim[variant]
 
 
