@@ -404,8 +404,11 @@ NDZIP_DEV void stage_hypercube_regs(const input_regs<W, Aligned> &regs, char *cu
 // tid % 8 of row i*32 + tid/8 (pieces 0-3 belong to the first cube, 4-7 to the second) -- so every wave-instruction
 // covers 8 full cache lines instead of 16 half lines (bare load loop: 0.098-0.101 ms vs 0.108-0.115 ms for 512^3 f32,
 // tools/membench.hip).  Offsets are affine in i: two z-planes per step in global memory, 2304 bytes in LDS.
-// `cube_stride` (bytes between the two cubes' staging regions) must be = 128 mod 256: the 16 lanes of a b128 group then
-// write rows r, r+1 of cube 0 into slots s..s+7 and of cube 1 into s+8..s+15.
+// `cube_stride` (bytes between the two cubes' staging regions) must be = 64 mod 128: a ds_write_b128 is served in groups of 8
+// consecutive lanes over 32 banks (MI355X guide, LDS table) = the 8 pieces of one row, 64 bytes for each cube -- which land on
+// the two halves of the bank space only if the cubes sit an odd multiple of 64 bytes apart.  (Round 1 had 128 mod 256, designed
+// for 64 banks: every staging write was a 2-way conflict, 128 of the 269 conflict cycles per hypercube of the 3D f32 kernel --
+// tools/lds_profile.py; its total of 33.9 % conflict cycles matches the 35 % the round-1 PMC run measured.)
 template<int Part = -1, int Split = 0>
 NDZIP_DEV void load_pair_regs(const uint32_t *__restrict__ in, const grid_geom &gg, uint64_t pair_origin, int tid,
         input_regs<uint32_t, true> &regs) {

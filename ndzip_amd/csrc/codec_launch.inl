@@ -35,8 +35,8 @@ struct tile_cfg {
     using W = typename word_of<T>::type;
     using L = lds_layout<W>;
     static constexpr uint32_t xchg_bytes = 32;  // per hypercube: 2 x uint32 + 2 x W
-    // bytes between the staging regions of a tile's hypercubes: = 128 mod 256, see stage_pair_regs
-    static constexpr uint32_t cube_stride = L::cube_bytes + (K > 1 ? 128 : 0);
+    // bytes between the staging regions of a tile's hypercubes: = 64 mod 128, see stage_pair_regs
+    static constexpr uint32_t cube_stride = L::cube_bytes + (K > 1 ? 64 : 0);
     static constexpr uint32_t smem_bytes = K * cube_stride + L::zero_bytes + K * xchg_bytes + 32;
 };
 
@@ -372,7 +372,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     char *cube = smem + grp * C::cube_stride;                             // staging of this group's hypercube
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);             // later: the K encoded runs, back to back
     char *zero_region = smem + K * C::cube_stride;
-    char *zero = zero_region + L::template zero_offset<Dims>();
+    // (the second hypercube's staging region sits 64 bytes = 4 sixteen-byte slots further round the banks than the first: so does
+    // the zero block its out-of-cube neighbour reads go to -- the whole region is zero)
+    char *zero = zero_region + L::template zero_offset<Dims>() + grp * (C::cube_stride % 256);
     uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
