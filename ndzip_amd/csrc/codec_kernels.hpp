@@ -133,19 +133,14 @@ struct __attribute__((packed, aligned(4))) unaligned16 {
 struct __attribute__((packed, aligned(4))) unaligned8 {
     u32x2_t v;
 };
-// Array input is read exactly once per launch: the aligned path uses the read-once (nt) policy (gfx950_lds.hpp); build with
-// -DNDZIP_PLAIN_INPUT_LOADS to A/B against the default cache policy.  Once = false: the caller reads only part of every cache
+// Array input is read exactly once per launch: the aligned path uses the read-once (nt) policy (gfx950_lds.hpp).  Once = false: the caller reads only part of every cache
 // line and another workgroup the rest (the 64-byte rows of an unpaired 3D f32 hypercube), so the line should stay cacheable.
 template<bool Aligned, bool Once = true>
 NDZIP_DEV vec16 global_load16(const void *p) {
     if constexpr (Aligned && !Once) {
         return *reinterpret_cast<const vec16 *>(p);
     } else if constexpr (Aligned) {
-#ifdef NDZIP_PLAIN_INPUT_LOADS
-        return *reinterpret_cast<const vec16 *>(p);
-#else
         return global_load16_once(p);
-#endif
     } else {
         const u32x4_t q = reinterpret_cast<const unaligned16 *>(p)->v;
         vec16 v;

@@ -58,10 +58,7 @@ NDZIP_DEV uint32_t desc_state(tile_desc d, uint32_t epoch) {
 // Look-back window: how many predecessor descriptors one hop reads (one per lane).  Every descriptor read is an
 // uncached 8-byte agent-scope load, i.e. its own fabric transaction: measured on 512^3 f32, 256 per hop costs 45 us
 // more kernel time than 64 per hop, 1024 per hop 170 us more (profiles/) -- narrow windows win.
-#ifndef NDZIP_LOOKBACK_LANES
-#define NDZIP_LOOKBACK_LANES 64
-#endif
-constexpr int lookback_lanes = NDZIP_LOOKBACK_LANES;
+constexpr int lookback_lanes = 64;
 // polls (with s_sleep between them, ~0.2 s in all) after which a look-back gives up and sets the error word; overridable only
 // so that the parity tests can force the give-up path
 #ifndef NDZIP_LOOKBACK_SPIN_LIMIT
@@ -115,23 +112,9 @@ NDZIP_DEV void publish_aggregate(desc_ref desc, uint32_t tile, uint32_t aggregat
     desc_store(desc.p + tile, desc_tag(desc.epoch, tile == 0 ? 2u : 1u) | aggregate);
 }
 
-// Phase stagger: all workgroups of a launch start in the same phase, and the ordered write-out keeps them within
-// one iteration of each other, so without help every CU alternates between "all resident workgroups load" and
-// "all compute" and HBM and the VALUs take turns idling.  Delaying workgroup b by (b / grid) of one iteration
-// spreads the phases; co-resident workgroups (b, b + 256, ...) then sit a fixed fraction of an iteration apart.
-NDZIP_DEV void stagger_start(uint32_t iteration_kcycles) {
-    if (iteration_kcycles == 0) return;
-    const uint64_t delay = static_cast<uint64_t>(iteration_kcycles) * 1024u * blockIdx.x / gridDim.x;
-    const uint64_t t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(4);
-}
-
 // first look-back window of `tile`, issued early so its latency hides behind other work (vector loads return in
 // order: issue this BEFORE any bulk load of the same wavefront)
-#ifndef NDZIP_LOOKBACK_PREFETCH
-#define NDZIP_LOOKBACK_PREFETCH 1
-#endif
-constexpr int lookback_prefetch = NDZIP_LOOKBACK_PREFETCH;  // windows read ahead of time (asynchronously)
+constexpr int lookback_prefetch = 1;  // windows read ahead of time (asynchronously)
 
 struct lookback_windows {
     tile_desc d[lookback_prefetch];
@@ -147,7 +130,7 @@ NDZIP_DEV void lookback_issue(desc_ref desc, uint32_t tile, int lane, lookback_w
 
 template<bool Preloaded>
 NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, uint32_t aggregate, uint32_t *err, int lane,
-        const lookback_windows &pre, uint32_t *hop_count = nullptr, uint32_t *poll_count = nullptr) {
+        const lookback_windows &pre) {
     if (tile == 0) return 0;
     if constexpr (Preloaded) {
         // Fast path, no memory operation and therefore no s_waitcnt: the preloaded windows reach an inclusive prefix
@@ -184,7 +167,6 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
             return sum;
         }
     }
-    if (hop_count) *hop_count += 100;  // (experiments: general path taken)
     uint32_t exclusive = 0;
     long long base = static_cast<long long>(tile) - 1;
     bool timed_out = false;
@@ -220,7 +202,6 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
                 wait_pos = __builtin_ctzll(invalid);
             }
             if (wait_pos < 0) break;
-            if (poll_count) *poll_count += 100;  // (experiments: x100 so that averages below 1 show)
             // the nearest missing predecessor: one lane polls it, then the window is read again
             if (lane == 0) {
                 const tile_desc *p = desc.p + (base - wait_pos);
@@ -243,7 +224,6 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
         const bool take = (!found || lane <= lf) && desc_state(d, desc.epoch) != 0;
         exclusive += wave_sum(take ? static_cast<uint32_t>(d) : 0u);
         if (found || timed_out) break;
-        if (hop_count) ++*hop_count;
         base -= lookback_lanes;
         ++hop;
     }
@@ -302,15 +282,6 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
     if (static_cast<uint32_t>(tid) < n - done) dst[done + tid] = src[done + tid];
 }
 
-// Ablation switches (tools/ablate.sh: NDZIP_HIP_EXP bit 0 no look-back, 1 no copy-out, 2 no plane writes, 4 phase timers,
-// bits 8.. start stagger) exist only in builds with -DNDZIP_EXP_ABLATION (or the phase timers' -DNDZIP_EXP_PHASE_TIMING):
-// as a run-time argument they cost the production kernel an SGPR and, at its register limit, a spilled pointer.
-#if defined(NDZIP_EXP_ABLATION) || defined(NDZIP_EXP_PHASE_TIMING)
-#define NDZIP_EXP_FLAGS(arg) const uint32_t exp_flags = (arg);
-#else
-#define NDZIP_EXP_FLAGS(arg) constexpr uint32_t exp_flags = 0u; (void) (arg);
-#endif
-
 // Tiles are handed out dynamically: `num_classes` ticket counters (class = blockIdx % num_classes, ticket n of class c
 // is tile n * num_classes + c), so tile order == start order, a tile's predecessors were all started before it, and
 // the look-back never depends on co-residency, dispatch order or placement.
@@ -336,11 +307,7 @@ template<typename T, int Dims>
 struct db_cfg {
     using C = tile_cfg<T, Dims>;
     static constexpr uint32_t smem_bytes = C::smem_bytes;
-#ifdef NDZIP_EXP_DB_WAVES
-    static constexpr int min_waves_per_simd = NDZIP_EXP_DB_WAVES;
-#else
     static constexpr int min_waves_per_simd = 3;
-#endif
 };
 
 // Paired: the two hypercubes of every tile are neighbours along x (3D, 32-bit, even hypercube count along x, aligned
@@ -349,19 +316,14 @@ template<typename T, int Dims, bool Aligned, bool Paired = false>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (db_cfg<T, Dims>::min_waves_per_simd))
 compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
         typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
-        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t exp_flags_arg, const uint32_t epoch) {
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t epoch) {
     const desc_ref desc{desc_base, epoch};
-    NDZIP_EXP_FLAGS(exp_flags_arg)
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
     using P = profile<T, Dims>;
     static_assert(P::B == 32, "register-buffered variant is for 32-bit words");
-#ifdef NDZIP_EXP_EARLY_VECTORS
-    constexpr int early_vectors = NDZIP_EXP_EARLY_VECTORS;
-#else
     constexpr int early_vectors = 4;  // of 8; measured on 512^3: 2 -> 0.221 ms, 4 -> 0.211, 6 -> 0.219 (spills)
-#endif
     constexpr int K = C::K;
     constexpr int NW = C::threads / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -378,7 +340,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
-    stagger_start(exp_flags >> 8);
 
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
     const uint32_t cls = blockIdx.x % num_classes;
@@ -395,20 +356,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     __syncthreads();
     uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
 
-#ifdef NDZIP_EXP_PHASE_TIMING
-    const bool timing = (exp_flags & 16u) != 0;
-    uint32_t ticks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t tick_dummy[2] = {0, 0};
-    uint64_t t_prev = timing ? __builtin_readcyclecounter() : 0;
-#define NDZIP_PHASE(i)                                          \
-    if (timing) {                                               \
-        const uint64_t now_ = __builtin_readcyclecounter();     \
-        ticks[i] += static_cast<uint32_t>(now_ - t_prev);       \
-        t_prev = now_;                                          \
-    }
-#else
-#define NDZIP_PHASE(i)
-#endif
     static_assert(!Paired || (Dims == 3 && sizeof(W) == 4 && K == 2 && Aligned), "paired loads: 3D, 32-bit, aligned rows");
     input_regs<W, Aligned> pre;
     if constexpr (Paired) {
@@ -446,10 +393,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         // it there: ISA + the ~3 k cycles of its "top of the iteration" phase timer).  Issued here it is in flight until the
         // resolve, most of an iteration later.
         lookback_windows window{};
-#ifndef NDZIP_EXP_WINDOW_BEHIND_PUBLISH
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
-#endif
-        NDZIP_PHASE(0)  // wait prefetch + stage + window issue
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
         const uint32_t next_tile = have_cur ? tile_of_ticket(misc[NW + 1], cls, num_classes) : tile;
         __builtin_amdgcn_sched_barrier(0);
@@ -466,16 +410,13 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         W r[vals_per_thread];
         uint32_t head = 0, count = 0, incl = 0;
         if (have_cur) {
-            NDZIP_PHASE(1)  // B1 + window issue
             stencil_residuals<T, Dims>(cube, zero, t, r);
             head = chunk_head32(r);
             count = active ? static_cast<uint32_t>(__builtin_popcount(head)) : 0u;
             incl = wave_inclusive_scan(count, lane);
             if (lane == 63) misc[wave] = incl;
         }
-        NDZIP_PHASE(2)  // stencil + head + chunk scan
         __syncthreads();  // B2: all stencil reads done (staging region reusable), wave totals known
-        NDZIP_PHASE(8)  // B2 wait
         uint32_t run_start = 0, aggregate = 0, my_len = 0, chunk_excl = 0;
         if (have_cur) {
 #pragma unroll
@@ -488,10 +429,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             chunk_excl = ((wave & 1) ? misc[2 * grp] : 0u) + incl - count;
             if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
-#ifdef NDZIP_EXP_WINDOW_BEHIND_PUBLISH  // experiment: the window a third of an iteration later, still ahead of the late prefetch
-        if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
-#endif
-        NDZIP_PHASE(9)  // aggregate + publish
         // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
         // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
         // live around the whole loop.
@@ -502,23 +439,18 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             load_hypercube_regs<T, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
         }
         __builtin_amdgcn_sched_barrier(0);
-        NDZIP_PHASE(7)  // late prefetch issue
         if (have_prev) {
             // the previous tile's planes leave the registers: compact them into the (now free) staging region
-            if (prev_active && !(exp_flags & 4u)) {
+            if (prev_active) {
                 write_planes32(tile_run + prev_run_start, prev_run_start, t, prev_head, prev_chunk_excl, planes);
             }
         }
-        NDZIP_PHASE(3)  // plane writes (prev)
         // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
-#ifndef NDZIP_EXP_TRANSPOSE_BEHIND_COPYOUT
         if (have_cur) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) planes[j] = r[j];
             transpose32(planes);
         }
-#endif
-        NDZIP_PHASE(5)  // transposes
         __builtin_amdgcn_sched_barrier(0);
         // The previous tile's prefix, as the LAST thing wavefront 0 does before B3: its predecessors (which may lag by
         // a good part of an iteration) have had the most time to publish, and its own late prefetch, which hipcc's
@@ -529,15 +461,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         // resolve right behind B1 0.238 (0.3 polls per tile, convoys); resolve between late prefetch and plane writes
         // 0.207; this order 0.201-0.205.
         if (have_prev && wave == 0) {
-            const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * static_cast<uint32_t>(K * P::max_hc_words)
-#ifdef NDZIP_EXP_PHASE_TIMING
-                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window, &ticks[10], &ticks[11]);
-#else
-                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
-#endif
+            const uint32_t exclusive = resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
             if (tid == 0) misc[NW] = exclusive;
         }
-        NDZIP_PHASE(6)  // resolve (prev)
         __syncthreads();  // B3: previous tile's runs complete in LDS, its prefix known
         // the ticket the NEXT iteration reads behind its B1 (it needs one iff it has a tile); in flight during the copy-out
         const bool draw = tid == 0 && next_tile < ntiles;
@@ -545,20 +471,12 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
             const uint32_t prefix = misc[NW];
-            if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
+            copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
             if (prev_active && t == 0) header[prev_hc] = prefix + prev_run_start + prev_my_len;  // offset_after(hc), common.hh:342-347
             // the last tile ends the body (store_stream_length, cuda_codec.inl:507-511)
             if (tid == 0 && prev_tile == ntiles - 1) store_stream_length(out_len, len_extra + prefix + prev_aggregate);
         }
-#ifdef NDZIP_EXP_TRANSPOSE_BEHIND_COPYOUT  // experiment: the transposes cover the copy-out's store acknowledgements (resolve earlier)
-        if (have_cur) {
-#pragma unroll
-            for (int j = 0; j < 32; ++j) planes[j] = r[j];
-            transpose32(planes);
-        }
-#endif
         if (draw) misc[NW + 1] = ticket_after_next;
-        NDZIP_PHASE(4)  // B3 + ticket + copy-out (prev)
         __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them; next ticket in LDS
         have_prev = have_cur;
         prev_tile = tile;
@@ -574,15 +492,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
     // visible); the descriptors need no clearing (epoch).
     release_tickets(tickets, num_classes, tid, err, out_len);
-#undef NDZIP_PHASE
-#ifdef NDZIP_EXP_PHASE_TIMING
-    if (timing && tid == 0) {
-        unsigned long long *acc = reinterpret_cast<unsigned long long *>(tickets) - 16;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) atomicAdd(acc + i, static_cast<unsigned long long>(ticks[i]));
-        atomicAdd(acc + 15, 1ull);
-    }
-#endif
 }
 
 // ---- the register-buffered deferred-write-out pipeline with 256 work-items per hypercube ("wide" mapping) ---------
@@ -602,9 +511,8 @@ template<typename W, int Dims, bool Aligned>
 __global__ void __launch_bounds__(wide_cfg<W>::threads, wide_cfg<W>::min_waves_per_simd)
 compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header, W *__restrict__ body,
         tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes, uint32_t *out_len, uint32_t len_extra, uint32_t *err,
-        const uint32_t exp_flags_arg, const uint32_t epoch) {
+        const uint32_t epoch) {
     const desc_ref desc{desc_base, epoch};
-    NDZIP_EXP_FLAGS(exp_flags_arg)
     using C = wide_cfg<W>;
     using L = wide::layout<W>;
     using E = wide::coding<W>;
@@ -680,13 +588,12 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         wide::load_regs<W, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
         __builtin_amdgcn_sched_barrier(0);
         // the previous tile's planes leave the registers: compact them into the (now free) staging region
-        if (have_prev && !(exp_flags & 4u)) E::write(prev_held, planes, run32, t);
+        if (have_prev) E::write(prev_held, planes, run32, t);
         // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
         if (have_cur) E::transpose(r, t, planes);
         __builtin_amdgcn_sched_barrier(0);
         if (have_prev && wave == 0) {
-            const uint32_t exclusive = (exp_flags & 1u) ? prev_tile * max_hc_words
-                                                        : resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
+            const uint32_t exclusive = resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
             if (tid == 0) misc[NW] = exclusive;
         }
         __syncthreads();  // B3: previous tile's run complete in LDS, its prefix known
@@ -695,7 +602,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
             const uint32_t prefix = misc[NW];
-            if (!(exp_flags & 2u)) copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
+            copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
             if (tid == 0) {
                 header[prev_tile] = prefix + prev_aggregate;  // offset_after(hc), common.hh:342-347
                 if (prev_tile == gg.nhc - 1) {
@@ -926,26 +833,6 @@ __global__ void debug_wave_scan_kernel(const uint32_t *in, uint32_t *out, uint32
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------
 
-// Experiment knobs (tools/ablate.sh, tools/ab.sh) exist only in builds with -DNDZIP_EXP_KNOBS; the production library reads
-// no environment variable here and always runs the configuration below.
-struct launch_knobs {
-    uint32_t exp_flags = 0;  // passed to the kernel; ignored by it unless built with -DNDZIP_EXP_ABLATION / _PHASE_TIMING
-    int blocks_per_cu = 0;   // 0 = as many as fit
-    bool paired = true;      // 3D f32: tiles of two x-neighbours fetched as 128-byte rows
-};
-inline const launch_knobs &knobs() {
-    static const launch_knobs k = [] {
-        launch_knobs v;
-#ifdef NDZIP_EXP_KNOBS
-        if (const char *e = getenv("NDZIP_HIP_EXP")) v.exp_flags = static_cast<uint32_t>(atoi(e));
-        if (const char *e = getenv("NDZIP_HIP_BPC")) v.blocks_per_cu = atoi(e);
-        if (getenv("NDZIP_HIP_NO_PAIRED")) v.paired = false;
-#endif
-        return v;
-    }();
-    return k;
-}
-
 // persistent grid, fully resident: workgroups per CU bounded by the occupancy query and by what the LDS alone admits
 template<typename Kernel>
 hipError_t persistent_blocks_per_cu(Kernel kernel, int threads, uint32_t smem_bytes, int *out) {
@@ -957,13 +844,11 @@ hipError_t persistent_blocks_per_cu(Kernel kernel, int threads, uint32_t smem_by
     if (e != hipSuccess) return e;
     const int by_lds = static_cast<int>((160u * 1024u) / smem_bytes);
     int n = api < by_lds ? api : by_lds;
-    if (n < 1) n = 1;
-    const int cap = knobs().blocks_per_cu;
-    *out = cap > 0 && cap < n ? cap : n;
+    *out = n < 1 ? 1 : n;
     return hipSuccess;
 }
 
-// Scratch layout (fixed, whatever the extent): [16 x u64 experiment counters][ticket counters, one per 128 B][1 line:
+// Scratch layout (fixed, whatever the extent): [16 x u64 reserved (lab builds: phase counters)][ticket counters, one per 128 B][1 line:
 // workgroups done][descriptors].  Nothing is cleared per launch: descriptors carry the launch epoch, the kernel zeroes the
 // ticket counters on its way out (the owner of the scratch zeroes everything once).
 template<typename Kernel, typename W>
@@ -972,30 +857,9 @@ hipError_t launch_persistent(Kernel kernel, int threads, uint32_t smem_bytes, in
     if (grid > ntiles) grid = ntiles;
     // (a grid smaller than the class count would leave classes without a workgroup, i.e. tiles nobody draws)
     const uint32_t num_classes = grid < ticket_classes ? 1u : ticket_classes;
-    const uint32_t exp_flags = knobs().exp_flags;
-#ifdef NDZIP_EXP_PHASE_TIMING
-    if (exp_flags & 16u) {
-        hipError_t e = hipMemsetAsync(a.desc, 0, 16 * sizeof(tile_desc), a.stream);
-        if (e != hipSuccess) return e;
-    }
-#endif
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg, a.header,
             static_cast<W *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16), num_classes, a.out_len,
-            a.len_extra, a.err, exp_flags, a.epoch);
-#ifdef NDZIP_EXP_PHASE_TIMING
-    if (exp_flags & 16u) {  // dump the per-phase cycle totals of this launch
-        unsigned long long acc[16];
-        (void) hipStreamSynchronize(a.stream);
-        (void) hipMemcpy(acc, a.desc, sizeof acc, hipMemcpyDeviceToHost);
-        static int dumps = 0;
-        if (dumps++ % 8 == 4) {
-            const double n = static_cast<double>(acc[15] ? acc[15] : 1) * ((ntiles + grid - 1) / grid);
-            fprintf(stderr, "[phase ticks per iteration, avg over %llu workgroups]", acc[15]);
-            for (int i = 0; i < 12; ++i) fprintf(stderr, " p%d=%.0f", i, static_cast<double>(acc[i]) / n);
-            fprintf(stderr, "\n");
-        }
-    }
-#endif
+            a.len_extra, a.err, a.epoch);
     return hipGetLastError();
 }
 
@@ -1021,7 +885,7 @@ hipError_t launch_compress_profile(const compress_args &a) {
         bool paired = false;
         auto kernel = compress_kernel_db<T, Dims, Aligned, false>;
         if constexpr (Dims == 3 && Aligned) {
-            paired = a.gg.g[2] % 2 == 0 && knobs().paired;
+            paired = a.gg.g[2] % 2 == 0;
             if (paired) kernel = compress_kernel_db<T, Dims, Aligned, true>;
         }
         static int blocks_per_cu_of[2] = {0, 0};

@@ -139,13 +139,18 @@ def test_pipelined_offloader_validates_arguments_before_touching_the_device():
 def test_production_library_reads_no_experiment_knobs():
     """The only environment variable the shipped library looks at is NDZIP_VERBOSE (the reference's own tracing switch,
     src/ndzip/common.hh:630-633): a stray variable on a benchmark box must not change which kernel runs.  The experiment
-    knobs of tools/ exist only in -DNDZIP_EXP_KNOBS builds."""
+    switches of tools/ are not in the product sources at all (tools/experiments/lab_scaffolding.patch)."""
     import re
 
     with open(hip.LIB_PATH, "rb") as f:
         blob = f.read()
     names = set(re.findall(rb"\x00(NDZIP_[A-Z0-9_]{3,})\x00", blob))  # whole C strings that look like a variable name
     assert names == {b"NDZIP_VERBOSE"}, names
+    csrc = os.path.join(ROOT, "ndzip_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp", ".inl")):
+            text = open(os.path.join(csrc, f)).read()
+            assert "NDZIP_EXP" not in text and "NDZIP_HIP_EXP" not in text, f"lab switch in product source {f}"
 
 
 def test_product_package_never_touches_the_wave_model():
@@ -163,3 +168,20 @@ def test_product_package_never_touches_the_wave_model():
                 assert "wavesim" not in text, os.path.join(base, f)
     for f in ("bench.py", "__graft_entry__.py", os.path.join("include", "ndzip_hip.h"), os.path.join("include", "ndzip_hip.hh")):
         assert "wavesim" not in open(os.path.join(root, f)).read(), f
+
+
+def test_lab_patch_still_applies():
+    """tools/experiments/lab_scaffolding.patch (ablation flags, knobs, phase timers, alternative orderings: what
+    tools/build_variant.sh --lab compiles) must keep applying to the product sources it was cut from."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    csrc = os.path.join(ROOT, "ndzip_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in os.listdir(csrc):
+            if f.endswith((".hip", ".hpp", ".inl")):
+                shutil.copy(os.path.join(csrc, f), tmp)
+        with open(os.path.join(ROOT, "tools", "experiments", "lab_scaffolding.patch")) as patch:
+            r = subprocess.run(["patch", "-p1", "--dry-run", "-d", tmp], stdin=patch, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr

@@ -1,6 +1,6 @@
 #!/bin/bash
 # timing experiments on the GPU box (compress only) on the variant built by
-#   tools/build_variant.sh knobs -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION
+#   tools/build_variant.sh knobs --lab -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION
 # (the production library reads no knobs):
 #   NDZIP_HIP_EXP bit0 = no look-back (fake offsets), bit1 = no copy-out, bit2 = no plane writes
 #   NDZIP_HIP_BPC = cap on resident workgroups per CU

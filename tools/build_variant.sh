@@ -1,14 +1,29 @@
 #!/bin/bash
-# Build a variant of the library for A/B work (CPU, no GPU needed): tools/build_variant.sh <name> [extra hipcc flags...]
+# Build a variant of the library for A/B work (CPU, no GPU needed): tools/build_variant.sh <name> [--lab] [extra hipcc flags...]
 #   -> ndzip_amd/_variants/<name>.so   (git-ignored; travels to the GPU box with gpurun)
-# e.g. tools/build_variant.sh knobs -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION   (what tools/ablate.sh needs)
+# --lab: compile a COPY of ndzip_amd/csrc with tools/experiments/lab_scaffolding.patch applied -- the experiment switches that
+# are deliberately not in the product sources (run-time ablation flags and environment knobs, per-phase cycle counters, the
+# alternative orderings of the f32 compress iteration, plain-policy input loads).  What they are selected with:
+#   -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION     NDZIP_HIP_EXP / NDZIP_HIP_BPC / NDZIP_HIP_NO_PAIRED (tools/ablate.sh)
+#   -DNDZIP_EXP_PHASE_TIMING                   per-phase cycle counters of the f32 compress iteration (NDZIP_HIP_EXP=16)
+#   -DNDZIP_EXP_WINDOW_BEHIND_PUBLISH, -DNDZIP_EXP_TRANSPOSE_BEHIND_COPYOUT, -DNDZIP_EXP_EARLY_VECTORS=n, -DNDZIP_EXP_DB_WAVES=n
+#   -DNDZIP_PLAIN_INPUT_LOADS                  default cache policy instead of nt for the read-once input
+# e.g. tools/build_variant.sh knobs --lab -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/ndzip_amd/_variants; mkdir -p "$out/obj_$name"
+src=$root/ndzip_amd/csrc
+if [ "$1" = "--lab" ]; then
+  shift
+  src=$out/obj_$name/src/ndzip_amd/csrc; rm -rf "$out/obj_$name/src"; mkdir -p "$src" "$out/obj_$name/src/include"
+  cp "$root"/ndzip_amd/csrc/*.hip "$root"/ndzip_amd/csrc/*.hpp "$root"/ndzip_amd/csrc/*.inl "$src"/
+  cp "$root"/include/ndzip_hip.h "$out/obj_$name/src/include/"
+  patch -s -p1 -d "$src" < "$root/tools/experiments/lab_scaffolding.patch"
+fi
 for u in kernels_f32 kernels_f64 capi; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" \
-      -c "$root/ndzip_amd/csrc/$u.hip" -o "$out/obj_$name/$u.o" &
+      -c "$src/$u.hip" -o "$out/obj_$name/$u.o" &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/$name.so" "$out/obj_$name"/*.o
