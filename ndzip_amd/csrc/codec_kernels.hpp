@@ -121,6 +121,39 @@ struct lds_layout {
 
 NDZIP_DEV void lds_write16(char *p, vec16 v) { *reinterpret_cast<vec16 *>(p) = v; }
 
+// Where the ENCODED RUN of a hypercube lives inside its (128-byte aligned) LDS region.  The compaction (encoder) and the
+// gather (decoder) touch it one 4-byte word per lane at a lane stride of "plane words the chunk keeps" -- for 64-bit profiles
+// 2 x kept planes dwords, an even number, and when most chunks of a wavefront keep the same count and that stride is a multiple
+// of 32 dwords (48 of 64 planes on the benchmark's 3D f64 grid) all 16 chunks of a lane group meet in the same banks:
+// tools/lds_profile.py prices that gather at 11x and the compaction at 9.5x their conflict-free cycles.  So 64-bit runs are
+// stored with the 16-byte slot s of every 128-byte block b at slot s ^ (b & 7): lane strides of 32 k dwords then spread over 8
+// slots, and the 16-byte staging stores and copy-out reads still move whole slots.  32-bit runs stay linear: their stride is
+// "planes kept", odd as often as even, and a swizzle makes the benchmark's 19-plane chunks slightly worse (2.7x -> 3.3x,
+// simulated over the oracle's streams).
+// The swizzle works on LDS byte ADDRESSES (gfx950_lds.hpp: lds_address / lds_pointer), so a region only has to start on a
+// 128-byte boundary of the LDS, and it costs a shift and one three-input bit operation per access.
+template<typename W>
+struct run_layout {
+    static constexpr bool swizzled = sizeof(W) == 8;
+    // where the byte with the linear LDS address `a` is kept
+    NDZIP_DEV static constexpr uint32_t at(uint32_t a) {
+        if constexpr (swizzled) {
+            return a ^ ((a >> 3) & 0x70u);
+        } else {
+            return a;
+        }
+    }
+    // the same for a pointer into the region
+    template<typename P>
+    NDZIP_DEV static P *ptr(P *linear) {
+        if constexpr (swizzled) {
+            return reinterpret_cast<P *>(lds_pointer(at(lds_address(linear))));
+        } else {
+            return linear;
+        }
+    }
+};
+
 // 16 / 8 bytes per lane from / to GLOBAL memory.  Aligned = the address is a multiple of the access size; otherwise only
 // of the element size (a row of an array whose extent is not a multiple of 4 elements starts anywhere): gfx950 runs in
 // unaligned access mode, so this is still ONE global_load/store_dwordx4 per lane -- it may touch one cache line more per
@@ -603,11 +636,15 @@ NDZIP_DEV void write_planes32(uint32_t *run, uint32_t run_word0, int t, uint32_t
 // ComplementInPlaneDomain: also undo complement_negative, but BEFORE the inverse transpose: flipping the low B-1 bits of
 // every negative value is "XOR every plane below the sign plane with the sign plane" -- B-1 operations on plane words
 // instead of 3 per value (ashr, lshr, xor) afterwards.
+// `region`: the LDS region the run was staged into, `run_off`: byte offset of the run's first word inside it (run_layout)
 template<typename T, int Dims, bool ComplementInPlaneDomain = false>
-NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typename profile<T, Dims>::word (&r)[vals_per_thread]) {
+NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *xchg, int t,
+        typename profile<T, Dims>::word (&r)[vals_per_thread]) {
     using P = profile<T, Dims>;
+    using R = run_layout<typename P::word>;
     constexpr int B = P::B;
     const int lane = t & 63, wave = t >> 6;
+    const char *cube = region + run_off;  // (32-bit profiles: the run is linear)
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(cube);
 
     // ---- phase 1: heads -> chunk offsets -> gather planes -> inverse transpose -----------------------------
@@ -650,7 +687,7 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
         const bool upper = (t & 1) == 0;
         const uint32_t half = upper ? 1u : 0u;
         const uint32_t c = static_cast<uint32_t>(t >> 1);
-        const uint32_t head_lo = in32[2 * c], head_hi = in32[2 * c + 1];
+        const uint32_t head_lo = *R::ptr(in32 + 2 * c), head_hi = *R::ptr(in32 + 2 * c + 1);
         const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(head_lo) + __builtin_popcount(head_hi));
         const uint32_t incl = wave_inclusive_scan(upper ? cnt : 0u, lane);
         if (lane == 63) xchg[wave] = incl;
@@ -661,19 +698,19 @@ NDZIP_DEV void decode_residuals(const char *cube, uint32_t *xchg, int t, typenam
         // the run, or the 8 bytes behind it that the staging region holds) and kept iff the bit is set -- three VALU
         // instructions per plane half instead of the mask / popcount / address / select of an indexed gather
         uint32_t hi[32], lo[32];
-        const char *p = cube + 8 * (base + cnt) + 4 * half;
+        uint32_t p = lds_address(cube) + 8 * (base + cnt) + 4 * half;  // linear LDS address; the word sits at R::at(p)
         int32_t kept_hi[32], kept_lo[32];  // 0 / -1 per plane (the kernel's occupancy is bound by LDS, not by these registers)
 #pragma unroll
         for (int i = 31; i >= 0; --i) {
             kept_lo[i] = opaque_vgpr(static_cast<int32_t>(head_lo << i) >> 31);
-            p += 8 * kept_lo[i];
-            lo[i] = *reinterpret_cast<const uint32_t *>(p);
+            p = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(p + 8 * kept_lo[i])));  // (one v_lshl_add_u32; not a running count)
+            lo[i] = *reinterpret_cast<const uint32_t *>(lds_pointer(R::at(p)));
         }
 #pragma unroll
         for (int i = 31; i >= 0; --i) {
             kept_hi[i] = opaque_vgpr(static_cast<int32_t>(head_hi << i) >> 31);
-            p += 8 * kept_hi[i];
-            hi[i] = *reinterpret_cast<const uint32_t *>(p);
+            p = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(p + 8 * kept_hi[i])));
+            hi[i] = *reinterpret_cast<const uint32_t *>(lds_pointer(R::at(p)));
         }
         lds_reads_issued_before_use(lo);
         lds_reads_issued_before_use(hi);
@@ -849,10 +886,10 @@ namespace ndzip_hip {
 
 template<typename T, int Dims, bool Aligned>
 NDZIP_DEV void decode_hypercube(typename profile<T, Dims>::word *__restrict__ out, const grid_geom &gg, uint64_t origin,
-        bool active, char *cube, const char *run, uint32_t *xchg, int t) {
-    // `run`: first word of the encoded run inside `cube` (4-byte aligned; consumed before `cube` is overwritten)
+        bool active, char *cube, uint32_t run_off, uint32_t *xchg, int t) {
+    // `run_off`: byte offset of the encoded run inside `cube` (run_layout; consumed before `cube` is overwritten with values)
     typename profile<T, Dims>::word r[vals_per_thread];
-    decode_residuals<T, Dims, true>(run, xchg, t, r);
+    decode_residuals<T, Dims, true>(cube, run_off, xchg, t, r);
     inverse_transform_hypercube<T, Dims, Aligned, true>(r, out, gg, origin, active, cube, xchg, t);
 }
 

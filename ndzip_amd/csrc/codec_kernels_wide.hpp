@@ -219,16 +219,18 @@ struct coding<uint64_t> {
         h.slot = 2 * pos + ((q & 2) ? 0u : 1u);  // lanes 0, 1: high dword of the plane word; lanes 2, 3: low dword
         return h;
     }
+    // `run32`: start of the run's LDS region (the run begins at its first byte); words go where run_layout<uint64_t> puts them
     NDZIP_DEV static void write(const held &h, const uint32_t (&planes)[planes_per_lane], uint32_t *run32, int t) {
+        using R = run_layout<uint64_t>;
         const int q = t & 3;
         const uint32_t c = static_cast<uint32_t>(t) >> 2;
-        if (q < 2) run32[2 * c + (q == 0 ? 1u : 0u)] = h.head_word;
-        uint32_t *p = run32 + h.slot;  // (a running pointer: one address increment per kept plane)
+        if (q < 2) *R::ptr(run32 + 2 * c + (q == 0 ? 1u : 0u)) = h.head_word;
+        uint32_t a = lds_address(run32 + h.slot);  // (a running linear LDS address: one increment per kept plane)
 #pragma unroll
         for (int i = 0; i < planes_per_lane; ++i) {
             if ((h.head_bits >> (31 - i)) & 1u) {
-                *p = planes[i];
-                p += 2;
+                *reinterpret_cast<uint32_t *>(lds_pointer(R::at(a))) = planes[i];
+                a += 8;
             }
         }
     }

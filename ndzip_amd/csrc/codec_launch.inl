@@ -250,15 +250,15 @@ NDZIP_DEV vec16 straddle(const vec16 &lo, const vec16 &hi) {
     return x;
 }
 
-template<int S, int Threads>
+template<typename R, int S, int Threads>
 NDZIP_DEV void copy_vectors(const vec16 *__restrict__ a, vec16 *__restrict__ d16, uint32_t nvec, int tid) {
     const char *base = reinterpret_cast<const char *>(a);
     for (uint32_t v = tid; v < nvec; v += Threads) {
-        const vec16 lo = lds_read16(base + 16 * v);
+        const vec16 lo = lds_read16(R::ptr(base + 16 * v));
         if constexpr (S == 0) {
             d16[v] = lo;
         } else {
-            d16[v] = straddle<S>(lo, lds_read16(base + 16 * v + 16));
+            d16[v] = straddle<S>(lo, lds_read16(R::ptr(base + 16 * v + 16)));
         }
     }
 }
@@ -268,18 +268,20 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
     constexpr uint32_t wpv = 16 / sizeof(W);
     uint32_t lead = (wpv - static_cast<uint32_t>((reinterpret_cast<uintptr_t>(dst) / sizeof(W)) % wpv)) % wpv;
     if (lead > n) lead = n;
-    if (static_cast<uint32_t>(tid) < lead) dst[tid] = src[tid];
+    using R = run_layout<W>;  // (`src` is the start of the run's region)
+    const auto word = [&](uint32_t i) { return *R::ptr(src + i); };
+    if (static_cast<uint32_t>(tid) < lead) dst[tid] = word(tid);
     const uint32_t nvec = (n - lead) / wpv;
     const vec16 *a = reinterpret_cast<const vec16 *>(src);
     vec16 *d16 = reinterpret_cast<vec16 *>(dst + lead);
     switch (lead * (sizeof(W) / 4)) {  // uint32 offset of the first vector inside its aligned LDS vector
-        case 0: copy_vectors<0, Threads>(a, d16, nvec, tid); break;
-        case 1: copy_vectors<1, Threads>(a, d16, nvec, tid); break;
-        case 2: copy_vectors<2, Threads>(a, d16, nvec, tid); break;
-        default: copy_vectors<3, Threads>(a, d16, nvec, tid); break;
+        case 0: copy_vectors<R, 0, Threads>(a, d16, nvec, tid); break;
+        case 1: copy_vectors<R, 1, Threads>(a, d16, nvec, tid); break;
+        case 2: copy_vectors<R, 2, Threads>(a, d16, nvec, tid); break;
+        default: copy_vectors<R, 3, Threads>(a, d16, nvec, tid); break;
     }
     const uint32_t done = lead + nvec * wpv;
-    if (static_cast<uint32_t>(tid) < n - done) dst[done + tid] = src[done + tid];
+    if (static_cast<uint32_t>(tid) < n - done) dst[done + tid] = word(done + tid);
 }
 
 // Tiles are handed out dynamically: `num_classes` ticket counters (class = blockIdx % num_classes, ticket n of class c
@@ -326,7 +328,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     constexpr int early_vectors = 4;  // of 8; measured on 512^3: 2 -> 0.221 ms, 4 -> 0.211, 6 -> 0.219 (spills)
     constexpr int K = C::K;
     constexpr int NW = C::threads / 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x);
     const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
@@ -518,8 +520,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     using E = wide::coding<W>;
     constexpr int NW = C::NW;
     constexpr int early_vectors = C::early_vectors;
-    constexpr uint32_t max_hc_words = hc_size + E::head_words;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x), t = tid;
     const int lane = tid & 63, wave = tid >> 6;
@@ -632,7 +633,7 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
     using L = typename C::L;
     using P = profile<T, Dims>;
     constexpr int K = C::K;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x);
     const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
@@ -676,7 +677,7 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
     uint32_t mis = 0;
     if (len == 0) {
         // padding group or corrupt entry: decode an all-zero hypercube so every LDS index stays in range
-        if (t < P::head_words) reinterpret_cast<W *>(cube)[t] = 0;
+        if (t < P::head_words) *run_layout<W>::ptr(reinterpret_cast<W *>(cube) + t) = 0;
     } else {
         const W *src = body + begin;
         mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(src) / sizeof(W)) % wpv);
@@ -691,12 +692,12 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
 #pragma unroll
         for (int i = 0; i < vec_per_thread; ++i) {
             const uint32_t j = static_cast<uint32_t>(i * threads_per_hc + t);
-            if (j < nvec) lds_write16(cube + 16 * j, v[i]);
+            if (j < nvec) lds_write16(run_layout<W>::ptr(cube + 16 * j), v[i]);
         }
     }
     __syncthreads();
     decode_hypercube<T, Dims, Aligned>(out, gg, active ? hc_origin<Dims>(gg, hc) : 0, active && len != 0, cube,
-            cube + mis * sizeof(W), xchg, t);
+            mis * static_cast<uint32_t>(sizeof(W)), xchg, t);
 }
 
 // ---- stage kernels for the parity tests: exactly one hypercube, through the SAME device functions the production kernels
@@ -712,7 +713,7 @@ debug_stage_kernel(int stage, const grid_geom gg, uint32_t hc, const typename wo
     using W = typename word_of<T>::type;
     using L = lds_layout<W>;
     using P = profile<T, Dims>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     char *cube = smem;
     char *zero_region = smem + L::cube_bytes;
     char *zero = zero_region + L::template zero_offset<Dims>();
@@ -745,10 +746,11 @@ debug_stage_kernel(int stage, const grid_geom gg, uint32_t hc, const typename wo
             if (t == 0) *out_len = len;
         }
     } else if (stage == debug_decode_residuals) {
-        W *dst = reinterpret_cast<W *>(cube);
-        for (uint32_t w = t; w < P::max_hc_words; w += threads_per_hc) dst[w] = in[w];
+        for (uint32_t w = t; w < P::max_hc_words; w += threads_per_hc) {
+            *run_layout<W>::ptr(reinterpret_cast<W *>(cube) + w) = in[w];
+        }
         __syncthreads();
-        decode_residuals<T, Dims>(cube, xchg, t, r);
+        decode_residuals<T, Dims>(cube, 0, xchg, t, r);
         for (int j = 0; j < vals_per_thread; ++j) out[t * 32 + j] = r[j];
     } else if (stage == debug_inverse_transform) {
         for (int j = 0; j < vals_per_thread; ++j) r[j] = in[t * 32 + j];
@@ -766,7 +768,7 @@ debug_stage_wide_kernel(int stage, const grid_geom gg, uint32_t hc, const uint64
     using L = wide::layout<W>;
     using E = wide::coding<W>;
     constexpr int NW = wide::threads / 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     char *cube = smem;
     char *zero_region = smem + L::cube_bytes;
     char *zero = zero_region + L::zero_offset;
@@ -800,8 +802,9 @@ debug_stage_wide_kernel(int stage, const grid_geom gg, uint32_t hc, const uint64
         E::transpose(r, t, planes);
         E::write(E::hold(t, head_a, head_b, E::head_words + chunk_excl), planes, reinterpret_cast<uint32_t *>(cube), t);
         __syncthreads();
-        const W *src = reinterpret_cast<const W *>(cube);
-        for (uint32_t w = t; w < total; w += wide::threads) out[w] = src[w];
+        for (uint32_t w = t; w < total; w += wide::threads) {
+            out[w] = *run_layout<W>::ptr(reinterpret_cast<const W *>(cube) + w);
+        }
         if (t == 0) *out_len = total;
     }
 }

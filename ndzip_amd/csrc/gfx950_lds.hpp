@@ -40,6 +40,18 @@ NDZIP_DEV vec16 lds_read16(const char *p) {
     return v;
 }
 
+// An LDS location as its 32-bit byte address and back (what a ds_ instruction takes): address arithmetic that is more than
+// pointer + offset -- the XOR swizzle of run_layout -- is done on this integer, so that it stays 32-bit VALU work and the
+// access stays a ds_ instruction (an integer round trip through a 64-bit generic pointer would turn it into a flat access).
+NDZIP_DEV uint32_t lds_address(const void *p) {
+    using lds_char = const __attribute__((address_space(3))) char;
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_char *) p));
+}
+NDZIP_DEV char *lds_pointer(uint32_t address) {
+    using lds_char = __attribute__((address_space(3))) char;
+    return (char *) reinterpret_cast<lds_char *>(static_cast<uintptr_t>(address));
+}
+
 // Scheduling fence for a batch of 32 word reads from LDS: every LDS access above it is issued before any of `w` is used
 // below it.  Left alone, hipcc interleaves a dependent-address gather with the uses of its results (ds_read_b32 ;
 // s_waitcnt lgkmcnt(0) ; v_and ; next address ; ds_read_b32 ...), one exposed LDS round trip per word; with the fence the

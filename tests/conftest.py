@@ -23,6 +23,25 @@ def pytest_configure(config):
         _enter_rehearsal()
 
 
+def pytest_sessionstart(session):
+    """CPU runs: build the kernels' functional model and its variants (spin limit 0, AddressSanitizer, LDS access profile) up
+    front and in parallel instead of one after the other inside the first tests that need them."""
+    config = session.config
+    if config.getoption("markexpr", "") == "gpu" and not config.getoption("--rehearse-on-model"):
+        return  # the hardware run does not touch the model
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests.wavesim import build as simbuild
+
+    jobs = [dict(), dict(variant="spin0", defines=("NDZIP_LOOKBACK_SPIN_LIMIT=0",)), dict(variant="asan", extra_flags=simbuild.ASAN_FLAGS),
+            dict(variant="ldsprof", defines=("WAVESIM_LDSPROF",), kernel_flags=simbuild.LDSPROF_FLAGS)]
+    try:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(lambda kw: simbuild.build(**kw), jobs))
+    except Exception as e:  # the tests that need a library rebuild it and fail with the compiler's message
+        print(f"wavesim prebuild failed: {e}")
+
+
 def pytest_collection_modifyitems(config, items):
     if not config.getoption("--rehearse-on-model"):
         return

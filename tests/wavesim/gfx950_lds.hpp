@@ -39,6 +39,10 @@ NDZIP_DEV vec16 lds_read16(const char *p) {
     return *reinterpret_cast<const vec16 *>(p);
 }
 
+// LDS byte address <-> pointer: here the offset inside the running workgroup's LDS array
+NDZIP_DEV uint32_t lds_address(const void *p) { return static_cast<uint32_t>(static_cast<const char *>(p) - smem); }
+NDZIP_DEV char *lds_pointer(uint32_t address) { return smem + address; }
+
 NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction scheduling only)
 
 NDZIP_DEV int32_t opaque_vgpr(int32_t x) { return x; }

@@ -80,7 +80,7 @@ static const wavesim_idx gridDim{{&wavesim::lane_grid_dim}};
 // ---- LDS: `extern __shared__ char smem[]` inside a kernel resolves to this per-workgroup-thread array ------------------
 namespace ndzip_hip {
 namespace {
-alignas(16) thread_local char smem[wavesim::lds_capacity];
+alignas(128) thread_local char smem[wavesim::lds_capacity];
 }
 }  // namespace ndzip_hip
 

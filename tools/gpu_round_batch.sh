@@ -22,7 +22,10 @@ TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summa
 #   winpub = look-back window issued behind the aggregate publish; trlate = transposes behind the copy-out (f32 only)
 V="main"; for v in plainloads winpub trlate dpp r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
 (timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt
-(timeout 600 bash tools/ab.sh "$V" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
+#   linear64 = 64-bit encoded runs linear in LDS (the round-1 layout) instead of XOR-swizzled (f64 only)
+V64="main"; for v in linear64 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V64="$V64 $v"; done
+(AB_MODE=both timeout 600 bash tools/ab.sh "$V64" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
+(AB_MODE=both timeout 600 bash tools/ab.sh "$V64" --shape 512,512,512 --dtype float64 2>&1) > ${O}_ab_variants_f64_3d.txt
 for i in 1 2 3 4 5 6; do
   echo "== run $i" >> ${O}_two_process_stress.txt
   HSA_ENABLE_IPC_MODE_LEGACY=0 CHECK_EACH=0 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
