@@ -31,7 +31,14 @@ def pytest_sessionstart(session):
         return  # the hardware run does not touch the model
     from concurrent.futures import ThreadPoolExecutor
 
+    from ndzip_amd import build as hipbuild
     from tests.wavesim import build as simbuild
+
+    try:  # a fresh checkout: cross-compile the product library the C-ABI / adaptor / CLI tests load (what __graft_entry__.build() does)
+        hipbuild.build()
+        hipbuild.build_test_variants()
+    except Exception as e:
+        print(f"product build failed: {e}")
 
     jobs = [dict(), dict(variant="spin0", defines=("NDZIP_LOOKBACK_SPIN_LIMIT=0",)), dict(variant="asan", extra_flags=simbuild.ASAN_FLAGS),
             dict(variant="ldsprof", defines=("WAVESIM_LDSPROF",), kernel_flags=simbuild.LDSPROF_FLAGS)]
