@@ -39,6 +39,12 @@ def pytest_sessionstart(session):
         hipbuild.build_test_variants()
     except Exception as e:
         print(f"product build failed: {e}")
+    try:  # the checkers: the C oracle and, where /root/reference exists, the real serial reference (oracle/_ref)
+        from oracle import oracle
+
+        oracle.build(ref=True)
+    except Exception as e:
+        print(f"oracle build failed: {e}")
 
     jobs = [dict(), dict(variant="spin0", defines=("NDZIP_LOOKBACK_SPIN_LIMIT=0",)), dict(variant="asan", extra_flags=simbuild.ASAN_FLAGS),
             dict(variant="ldsprof", defines=("WAVESIM_LDSPROF",), kernel_flags=simbuild.LDSPROF_FLAGS)]
