@@ -294,3 +294,30 @@ def test_f32_3d_with_an_odd_hypercube_count_along_x_takes_the_unpaired_loads(sha
     """Aligned rows but an odd number of hypercubes along x: tiles 2m, 2m+1 are not x-neighbours everywhere, so the launcher
     must pick the unpaired kernel (compress_kernel_db<float, 3, true, false>)."""
     _check(synth_numpy(shape, np.float32, seed=41, noise_mask=0xFFF), cus=3, blocks_per_cu=2)
+
+
+@pytest.mark.parametrize("resident", [16, 20])
+def test_sixteen_ticket_classes_with_a_partly_resident_grid(resident, monkeypatch):
+    """The same with 16 ticket classes (grids of 16+ workgroups): what the scheme needs is one live drawer per class, i.e. the
+    first 16 workgroups resident ("Tile order = ticket order"); workgroups 16.. of the 24 may start late or never."""
+    monkeypatch.setenv("WAVESIM_MAX_RESIDENT", str(resident))
+    for dtype, shape in ((np.float32, (6 * 16, 4 * 16, 4 * 16)), (np.float64, (7 * 64, 6 * 64 + 5))):
+        data = synth_numpy(shape, dtype, seed=10)
+        want = oracle.compress(data)
+        got = sim.compress(data, cus=8, blocks_per_cu=3)
+        assert len(got) == len(want) and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("resident", [1, 3, 7])
+def test_grid_larger_than_what_is_resident(resident, monkeypatch):
+    """Tiles are drawn with tickets, never assigned to a block index: a launch whose grid is only partly resident (another
+    stream's kernels occupy CUs; here: 24 workgroups, `resident` of them at a time, the others start when those have exited)
+    completes with the right stream -- the late workgroups find no ticket left and leave.  A statically assigned first tile
+    would hang here (its successors' look-back waits for a workgroup that cannot start)."""
+    monkeypatch.setenv("WAVESIM_MAX_RESIDENT", str(resident))
+    for dtype, shape in ((np.float32, (3 * 16, 2 * 16, 4 * 16)), (np.float64, (5 * 64 + 3, 3 * 64))):
+        data = synth_numpy(shape, dtype, seed=9)
+        want = oracle.compress(data)
+        got = sim.compress(data, cus=8, blocks_per_cu=3)
+        assert len(got) == len(want) and np.array_equal(got, want)
+        assert same_bits(sim.decompress(want, dtype, shape), data)
