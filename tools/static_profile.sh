@@ -23,6 +23,14 @@ for k in "f32 compress_kernel_dbIfLi3ELb1ELb1E" "f32 compress_kernel_dbIfLi1ELb1
     python "$root/tools/isa_cost.py" "$tmp/${v}_$1.s" "$2" | sed -n '2,3p;6p'
   done
 done
+echo "# decompress kernels (one pass per workgroup, no main loop): the whole kernel's issue budget (depth 0)"
+for k in "f32 decompress_kernelIfLi3ELb1E" "f32 decompress_kernelIfLi1ELb1E" "f64 decompress_kernelIdLi2ELb1E" "f64 decompress_kernelIdLi3ELb1E"; do
+  set -- $k
+  for v in base head; do
+    echo "## $v  $2"
+    python "$root/tools/isa_cost.py" "$tmp/${v}_$1.s" "$2" | sed -n '2p'
+  done
+done
 echo "# hipcc -Rpass-analysis=kernel-resource-usage (head): VGPRs / scratch / occupancy of the codec kernels"
 for t in f32 f64; do
   python - "$tmp/head_$t.remarks" <<'PY'
