@@ -185,3 +185,27 @@ def test_lab_patch_still_applies():
         with open(os.path.join(ROOT, "tools", "experiments", "lab_scaffolding.patch")) as patch:
             r = subprocess.run(["patch", "-p1", "--dry-run", "-d", tmp], stdin=patch, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_shipped_kernels_use_no_flat_or_scratch_memory(tmp_path):
+    """Disassembly of the gfx950 code objects inside the built library: every LDS access is a ds_ instruction and every global one
+    a global_ instruction (an address computed through a generic pointer would show up as flat_*, a register spill as scratch_*),
+    the read-once input carries the nt policy, and the look-back's descriptor traffic is write-through / system-coherent (sc1)."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    lib = shutil.copy(hip.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, capture_output=True, text=True, check=True)
+    objects = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(objects) >= 3, os.listdir(tmp_path)
+    text = ""
+    for f in objects:
+        text += subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
+    ops = [line.split("\t")[1].split()[0] for line in text.splitlines() if line.startswith("\t") and len(line.split("\t")) > 1 and line.split("\t")[1].strip()]
+    assert len(ops) > 20000
+    assert not [o for o in ops if o.startswith(("flat_", "scratch_"))]
+    assert sum(o.startswith("ds_") for o in ops) > 1000 and sum(o.startswith("global_load") for o in ops) > 300
+    assert text.count(" nt") > 100 and text.count(" sc1") > 50
