@@ -643,7 +643,7 @@ NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *
     using P = profile<T, Dims>;
     using R = run_layout<typename P::word>;
     constexpr int B = P::B;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = wave_uniform(t >> 6);
     const char *cube = region + run_off;  // (32-bit profiles: the run is linear)
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(cube);
 
@@ -742,7 +742,7 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
     using P = profile<T, Dims>;
     using W = typename P::word;
     using L = lds_layout<W>;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = wave_uniform(t >> 6);
     if constexpr (!AlreadyComplemented) {
 #pragma unroll
         for (int j = 0; j < 32; ++j) r[j] = complement_negative(r[j]);

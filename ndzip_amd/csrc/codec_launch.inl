@@ -331,8 +331,8 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x);
-    const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int grp = wave / (threads_per_hc / 64), t = tid % threads_per_hc;
     char *cube = smem + grp * C::cube_stride;                             // staging of this group's hypercube
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);             // later: the K encoded runs, back to back
     char *zero_region = smem + K * C::cube_stride;
@@ -523,7 +523,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x), t = tid;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;  // (as a scalar -- wave_uniform -- this kernel gains nothing: measured on its ISA)
     char *cube = smem;
     uint32_t *run32 = reinterpret_cast<uint32_t *>(smem);  // later: the encoded run (f64: as uint32 halves of its words)
     char *zero_region = smem + L::cube_bytes;
@@ -636,7 +636,7 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
     extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x);
-    const int grp = tid / threads_per_hc, t = tid % threads_per_hc;
+    const int grp = wave_uniform(tid / threads_per_hc), t = tid % threads_per_hc;
     char *cube = smem + grp * C::cube_stride;
     uint32_t *xchg = reinterpret_cast<uint32_t *>(smem + K * C::cube_stride + L::zero_bytes) + grp * (C::xchg_bytes / 4);
 

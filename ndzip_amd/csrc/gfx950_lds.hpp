@@ -52,6 +52,11 @@ NDZIP_DEV char *lds_pointer(uint32_t address) {
     return (char *) reinterpret_cast<lds_char *>(static_cast<uintptr_t>(address));
 }
 
+// A value that is the same in every lane of the wavefront (a wave index, a hypercube-of-the-tile index), as a scalar: what is
+// tested on it becomes an s_cmp and a scalar branch instead of a v_cmp into a 64-bit lane mask that has to be kept (or spilled
+// and reloaded lane by lane) for as long as the condition is used.
+NDZIP_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 // Scheduling fence for a batch of 32 word reads from LDS: every LDS access above it is issued before any of `w` is used
 // below it.  Left alone, hipcc interleaves a dependent-address gather with the uses of its results (ds_read_b32 ;
 // s_waitcnt lgkmcnt(0) ; v_and ; next address ; ds_read_b32 ...), one exposed LDS round trip per word; with the fence the

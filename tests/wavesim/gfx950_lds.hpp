@@ -43,6 +43,8 @@ NDZIP_DEV vec16 lds_read16(const char *p) {
 NDZIP_DEV uint32_t lds_address(const void *p) { return static_cast<uint32_t>(static_cast<const char *>(p) - smem); }
 NDZIP_DEV char *lds_pointer(uint32_t address) { return smem + address; }
 
+NDZIP_DEV int wave_uniform(int x) { return x; }  // (the caller's claim; the value is the lane's own)
+
 NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction scheduling only)
 
 NDZIP_DEV int32_t opaque_vgpr(int32_t x) { return x; }
