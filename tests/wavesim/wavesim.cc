@@ -163,15 +163,31 @@ void prepare_fiber(lane_ctx &l) {
     l.sp = sp;
 }
 
+// Fiber stacks are kept across launches (a process-wide free list): mapping, first-touching and unmapping 256 of them per
+// workgroup thread and launch was most of the model's system time.
+std::mutex g_stack_mutex;
+std::vector<void *> g_free_stacks;
+
 struct thread_stacks {
     std::vector<void *> stacks;
     ~thread_stacks() {
-        for (void *s : stacks) munmap(s, stack_bytes);
+        std::lock_guard<std::mutex> lock(g_stack_mutex);
+        g_free_stacks.insert(g_free_stacks.end(), stacks.begin(), stacks.end());
     }
     void *get(size_t i) {
         while (stacks.size() <= i) {
-            void *p = mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-            if (p == MAP_FAILED) die("cannot map a fiber stack");
+            void *p = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(g_stack_mutex);
+                if (!g_free_stacks.empty()) {
+                    p = g_free_stacks.back();
+                    g_free_stacks.pop_back();
+                }
+            }
+            if (!p) {
+                p = mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+                if (p == MAP_FAILED) die("cannot map a fiber stack");
+            }
             stacks.push_back(p);
         }
         return stacks[i];
@@ -193,7 +209,7 @@ struct lds_guard {
     size_t used;
     lds_guard(const launch_cfg &cfg) : base(cfg.lds_base()), used(cfg.lds_bytes) {
         if (used > lds_capacity) die("launch asks for more LDS than a CU has");
-        memset(base, 0xA5, lds_capacity);
+        memset(base, 0xA5, used);  // (what the launch may touch; the rest is out of bounds for it)
 #ifdef WAVESIM_ASAN
         __asan_poison_memory_region(base + used, lds_capacity - used);
 #endif
@@ -386,7 +402,7 @@ uint32_t update_dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask
 }
 
 void sleep_hint() {
-    std::this_thread::yield();
+    if ((g_self->tid & 63u) == 0) std::this_thread::yield();  // (one OS yield per wavefront and poll, not one per lane)
     yield_to_scheduler();
 }
 
