@@ -12,8 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_gpu_suite_passes_on_the_functional_model():
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "--rehearse-on-model", "-q", "-x", "-p", "no:cacheprovider"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    cmd = [sys.executable, "-m", "pytest", "tests", "-m", "gpu", "--rehearse-on-model", "-q", "-x", "-p", "no:cacheprovider"]
+    try:  # (three test processes side by side when pytest-xdist is there: the full-size cases dominate and overlap)
+        import xdist  # noqa: F401
+
+        cmd += ["-n", "3"]
+    except ImportError:
+        pass
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     m = re.search(r"(\d+) passed", tail)
