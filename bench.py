@@ -304,6 +304,12 @@ def cpu_legs(host_grid, budget_s):
         except Exception as e:  # a reported extra must never cost the GPU number
             out[name] = {"value": None, "unit": "GB/s", "cores": 0, "kind": kind, "sample": f"failed: {type(e).__name__}: {e}"}
 
+    # which checker is timed, and why: the compiled reference (oracle/_ref/libndzip_ref.so, built from /root/reference where that
+    # exists and shipped as a binary) when it is there, else the C restatement (oracle/libndzip_oracle.so)
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libndzip_ref.so")
+    why = (f"kind=reference: {os.path.relpath(ref_so, ROOT)} is present" if oracle.have_ref()
+           else f"kind=port: {os.path.relpath(ref_so, ROOT)} is absent (not built here and not shipped), timing the C restatement")
+    print(f"[bench] cpu_baseline {why}", file=sys.stderr, flush=True)
     if oracle.have_ref():
         guarded("cpu_baseline", lambda: cpu_reference_blocks(host_grid, cores, budget_s), "reference")
         guarded("cpu_port_openmp", lambda: cpu_port_openmp(host_grid, cores, min(budget_s, 8.0)), "port")
@@ -316,6 +322,8 @@ def cpu_legs(host_grid, budget_s):
                 "reference")
     else:
         guarded("cpu_baseline", lambda: cpu_port_openmp(host_grid, cores, budget_s), "port")
+    if isinstance(out.get("cpu_baseline"), dict):
+        out["cpu_baseline"]["why_kind"] = why
     return out
 
 
@@ -538,16 +546,26 @@ def main(argv=None):
         if t_decomp is not None:
             result["per_gpu"]["decompress_GBps"] = round(raw_total / world / t_decomp / 1e9, 2)
             result["per_gpu"]["decompress_frac_of_hbm_peak"] = round(raw_total / world / t_decomp / 1e9 / HBM_PEAK_GBPS, 4)
+        # HBM bytes per launch from the PMC passes (tools/pmc.sh -> profiles/traffic.json): only counters that were taken on
+        # THESE kernels (fingerprint of the device-code sources) may stand next to this run's launch time; anything else is null
+        result["roofline"]["traffic"] = None
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and not args.lib:
             try:
+                from ndzip_amd.build import kernels_fingerprint
+
                 with open(traffic_file) as f:
                     tr = json.load(f)
                 key = f"{np_dtype.name}-{'x'.join(map(str, slabs[0].extent))}"
                 if key in tr:
-                    which = "decompress_hbm_bytes_per_launch" if mode == "decompress" else "compress_hbm_bytes_per_launch"
-                    result["roofline"]["traffic"] = tr[key].get(which)
-                    result["roofline"]["traffic_source"] = tr[key].get("source")
+                    have, built = tr[key].get("kernels"), kernels_fingerprint()
+                    if have == built:
+                        which = "decompress_hbm_bytes_per_launch" if mode == "decompress" else "compress_hbm_bytes_per_launch"
+                        result["roofline"]["traffic"] = tr[key].get(which)
+                        result["roofline"]["traffic_source"] = tr[key].get("source")
+                    else:
+                        result["roofline"]["traffic_source"] = (f"none: profiles/traffic.json holds counters of kernels {have}, "
+                                                                f"this tree's are {built} (re-run tools/pmc.sh)")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

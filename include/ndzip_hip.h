@@ -218,7 +218,9 @@ NDZIP_HIP_API int ndzip_hip_stream_words(int dtype, int dims, const uint32_t *ex
 NDZIP_HIP_API int ndzip_hip_chunked_plan(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, uint64_t *rows_per_chunk,
         uint64_t *num_chunks, uint64_t *length_bound_words);
 
-/* `streams` must hold the plan's length bound (`capacity_words`); *total_words = words of the concatenation */
+/* `streams` has room for `capacity_words`: the plan's length bound always suffices, and any capacity that holds the streams
+ * actually produced is enough (each slab is copied from the device straight behind its predecessors once its exact length is
+ * known; NDZIP_HIP_ERR_CAPACITY otherwise).  *total_words = words of the concatenation */
 NDZIP_HIP_API int ndzip_hip_chunked_compress(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, const void *data,
         void *streams, uint64_t capacity_words, uint64_t *total_words, uint64_t *kernel_ns);
 

@@ -64,6 +64,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def kernels_fingerprint() -> str:
+    """Short hash over the device-code sources (csrc/*.hip, *.hpp, *.inl) and the compiler flags: what a set of hardware
+    counters was measured on.  profiles/traffic.json entries carry it, and bench.py reports `roofline.traffic` only for an
+    entry whose fingerprint is the one of the sources in this tree (counters of other kernels next to a fresh launch time would
+    be a made-up number)."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp", ".inl")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def kernel_resources() -> dict:
     """{demangled-ish kernel name: {"vgprs", "scratch", "occupancy", "sgpr_spill"}} of the last build of every translation unit
     (hipcc -Rpass-analysis=kernel-resource-usage).  A compress kernel with scratch is a performance bug: a scratch reload is a

@@ -13,15 +13,19 @@
 //   * the summary line reports the true raw size (the reference multiplies by the chunk count twice, compress.cc:50-51).
 //   * a trailing partial array is an error for compression, as in the reference (io.cc read_exact).
 //
-// I/O follows src/io/io.cc: regular files are memory-mapped unless `--no-mmap` is given (mmap_input_stream /
-// mmap_output_stream, io.cc:118-256: the input is mapped once and handed to the device copy in place; the output file grows by
-// one mapped window per array and is truncated to its final length), stdin / stdout and `--no-mmap` go through stdio
-// (stdio_input_stream / stdio_output_stream, io.cc:17-116) and pinned buffers.
+// I/O follows src/io/io.cc, with one difference in the default: files, stdin and stdout go through stdio and pinned staging
+// buffers (stdio_input_stream / stdio_output_stream, io.cc:17-116) unless `--mmap` is given; `--no-mmap` -- the reference's
+// switch, whose default is the mapped path (compress.cc:150,211-216) -- is accepted and selects what already is the default.
+// With `--mmap` regular files are memory-mapped (mmap_input_stream / mmap_output_stream, io.cc:118-256: the input is mapped once
+// and handed to the device copy in place; the output file grows by one mapped window per array and is truncated to its final
+// length).  The mapped path asks the HIP runtime to copy to and from file-backed mappings, which it has to stage page by page;
+// it stays opt-in until it has been run and timed against the pinned path on the hardware.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 #include <cinttypes>
@@ -46,7 +50,7 @@ struct options {
     std::string output = "-";
     int slots = 3;
     bool quiet = false;
-    bool use_mmap = true;  // compress.cc:150,211-216: memory-mapped I/O unless --no-mmap
+    bool use_mmap = false;  // --mmap: memory-mapped file I/O (the reference's default, compress.cc:150,211-216)
 };
 
 [[noreturn]] void usage_error(const std::string &msg, const char *argv0) {
@@ -62,7 +66,8 @@ struct options {
             "  -i [ --input ] arg        input file (default '-' is stdin)\n"
             "  -o [ --output ] arg       output file (default '-' is stdout)\n"
             "  --slots arg               arrays in flight on the device (default 3)\n"
-            "  --no-mmap                 do not use memory-mapped I/O (stdin / stdout never are)\n"
+            "  --mmap                    memory-mapped I/O for regular files (stdin / stdout never are)\n"
+            "  --no-mmap                 stdio and pinned staging buffers (the default)\n"
             "  -q [ --quiet ]            no summary line\n");
     exit(EXIT_FAILURE);
 }
@@ -113,6 +118,8 @@ options parse(int argc, char **argv) {
             o.output = value("--output");
         } else if (a == "--slots") {
             o.slots = static_cast<int>(parse_u32(value("--slots"), argv[0]));
+        } else if (a == "--mmap") {
+            o.use_mmap = true;
         } else if (a == "--no-mmap") {
             o.use_mmap = false;
         } else if (a == "-q" || a == "--quiet") {
@@ -236,9 +243,12 @@ struct stdio_output final : output {  // io.cc:69-116
 
 // The file grows by one mapped window per array (ftruncate + mmap of the page-aligned range that holds it) and is truncated to
 // the committed length at the end -- mmap_output_stream (io.cc:178-256) with several windows alive at a time, because several
-// arrays are in flight.  Windows are handed out at a provisional offset = committed bytes + the maximum sizes of the arrays in
-// flight before this one; an array that turns out shorter than its maximum (compression) makes the later in-flight windows sit
-// too far back, so commit() moves such an array forward to its final place (one memmove inside the page cache).
+// arrays are in flight and are produced in place by concurrent device copies.  A window is handed out behind the window of the
+// array before it (each as long as that array's MAXIMUM size: live windows must not overlap); an array that turns out shorter
+// than its maximum leaves every later window too far back, so commit() copies such an array forward to its final place and
+// gives the blocks of its provisional place back to the file system (FALLOC_FL_PUNCH_HOLE, best effort).  The file's LENGTH
+// therefore reaches the sum of the maxima until finish() truncates it, but it is sparse: the blocks in use stay near the
+// committed bytes plus the arrays in flight.
 struct mapped_output final : output {
     struct win {
         void *base;      // mmap result
@@ -271,13 +281,19 @@ struct mapped_output final : output {
         if (live.empty() || live.front().data != data) throw std::runtime_error("output windows are committed in hand-out order");
         win w = live.front();
         live.erase(live.begin());
-        if (w.offset != committed && bytes) {  // an earlier array was shorter than its window: move this one up to its place
+        const bool moved = w.offset != committed && bytes;
+        if (moved) {  // an earlier array was shorter than its window: copy this one up to its place (forward copy, destination first)
             if (pwrite(fd, w.data, bytes, static_cast<off_t>(committed)) != static_cast<ssize_t>(bytes)) {
                 throw std::runtime_error(std::string("pwrite: ") + strerror(errno));
             }
         }
         if (munmap(w.base, w.map_len) == -1) throw std::runtime_error(std::string("munmap: ") + strerror(errno));
         committed += bytes;
+        if (moved) {
+            // whole pages of the provisional place that lie behind everything committed so far
+            const size_t from = (std::max(w.offset, committed) + page - 1) / page * page, to = (w.offset + bytes) / page * page;
+            if (to > from) (void) fallocate(fd, FALLOC_FL_PUNCH_HOLE | FALLOC_FL_KEEP_SIZE, static_cast<off_t>(from), static_cast<off_t>(to - from));
+        }
     }
     void finish() override {
         if (ftruncate(fd, static_cast<off_t>(committed)) == -1) throw std::runtime_error(std::string("ftruncate: ") + strerror(errno));

@@ -56,17 +56,26 @@ bool valid_dims(int dims) { return dims >= 1 && dims <= 3; }
 size_t word_bytes(int dtype) { return dtype == NDZIP_HIP_F32 ? 4 : 8; }
 uint32_t header_words_for(int dtype, uint32_t nhc) { return dtype == NDZIP_HIP_F32 ? nhc : (nhc + 1) / 2; }
 
-int ensure_device(int *num_cus) {
+// The calling thread's current device: its ordinal, compute units and accelerator complexes (XCDs, each with its own L2;
+// 8 on an MI355X in SPX mode -- asked of the runtime, not assumed: a partitioned device reports fewer).
+int ensure_device(int *num_cus, int *device = nullptr, int *num_xcds = nullptr) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
         (void) hipGetLastError();
         return fail(NDZIP_HIP_ERR_NO_DEVICE, "no HIP device visible: the ndzip HIP back-end has no CPU fallback");
     }
-    if (num_cus) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int dev = 0;
+    if (num_cus || device || num_xcds) HIP_TRY(hipGetDevice(&dev));
+    if (device) *device = dev;
+    if (num_cus) HIP_TRY(hipDeviceGetAttribute(num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (num_xcds) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || n < 1) {
+            (void) hipGetLastError();
+            n = 1;  // unknown: tiles in plain order (only locality depends on it)
+        }
+        *num_xcds = n;
     }
     return NDZIP_HIP_OK;
 }
@@ -99,14 +108,14 @@ template<typename W, bool Pack>
 __global__ void border_kernel(W *data, W *body, const uint32_t *header, uint32_t nhc, const uint32_t *header_base, border_geom bg,
         uint32_t *out_len, uint32_t len_extra, uint32_t *err, uint32_t body_words) {
     const uint64_t start = nhc ? header[nhc - 1] - (header_base ? *header_base : 0u) : 0u;  // stream<Profile>::border(), common.hh:365
+    bool corrupt = false;
     if (!Pack) {
-        // unpacking trusts the last header entry only as far as the format allows (same rule as decompress_kernel)
+        // unpacking trusts the last header entry only as far as the format allows (same rule as decompress_kernel); a border
+        // that cannot be located is written as zeros, with the error word set, rather than left as whatever the buffer held
         constexpr uint64_t B = sizeof(W) * 8;
         const uint64_t lo = static_cast<uint64_t>(nhc) * (hc_size / B), hi = static_cast<uint64_t>(nhc) * (hc_size / B * (B + 1));
-        if (start < lo || start > hi || start + bg.count > body_words) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, 2u);
-            return;
-        }
+        corrupt = start < lo || start > hi || start + bg.count > body_words;
+        if (corrupt && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, 2u);
     }
     W *border = body + start;
     const uint64_t zpart = bg.cz * bg.per_z;
@@ -127,7 +136,7 @@ __global__ void border_kernel(W *data, W *body, const uint32_t *header, uint32_t
         if (Pack) {
             border[i] = data[src];
         } else {
-            data[src] = border[i];
+            data[src] = corrupt ? W{0} : border[i];
         }
     }
     // with zero hypercubes nobody else writes the stream length (store_stream_length, cuda_codec.inl:507-511)
@@ -174,10 +183,15 @@ hipError_t launch_border(int dtype, void *data, void *body, const uint32_t *head
     return hipGetLastError();
 }
 
-int check_error_word(uint32_t *d_err, hipStream_t stream) {
+// error word bits
+constexpr uint32_t err_lookback_timeout = 1u, err_corrupt_header = 2u;
+
+int check_error_word(uint32_t *d_err, hipStream_t stream, uint32_t *bits = nullptr) {
     uint32_t host = 0;
+    if (bits) *bits = 0;
     HIP_TRY(hipMemcpyAsync(&host, d_err, sizeof host, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (bits) *bits = host;
     if (host != 0) {
         HIP_TRY(hipMemsetAsync(d_err, 0, sizeof host, stream));
         char buf[160];
@@ -198,6 +212,7 @@ struct ndzip_hip_compressor {
     tile_desc *desc;
     uint32_t *err;
     int num_cus;
+    int device;          // the device the handle was created on (and launches on)
     size_t desc_count;   // entries of `desc`
     uint32_t epoch;      // launches on `desc` so far (descriptor epoch, codec_launch.inl)
 };
@@ -207,6 +222,7 @@ struct ndzip_hip_decompressor {
     int dims;
     hipStream_t stream;
     uint32_t *err;
+    int num_xcds;
 };
 
 extern "C" {
@@ -257,9 +273,9 @@ int ndzip_hip_compressor_create(int dtype, int dims, uint32_t max_num_hypercubes
     *out = nullptr;
     if (!valid_dtype(dtype)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid dtype");
     if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");  // common.hh:642
-    int cus = 0;
-    if (int s = ensure_device(&cus)) return s;
-    auto *c = new ndzip_hip_compressor{dtype, dims, max_num_hypercubes, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, cus, 0, 0};
+    int cus = 0, device = 0;
+    if (int s = ensure_device(&cus, &device)) return s;
+    auto *c = new ndzip_hip_compressor{dtype, dims, max_num_hypercubes, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, cus, device, 0, 0};
     const uint32_t tiles = dtype == NDZIP_HIP_F32 ? compress_num_tiles<float>(dims, max_num_hypercubes)
                                                   : compress_num_tiles<double>(dims, max_num_hypercubes);
     c->desc_count = static_cast<size_t>(tiles) + scratch_extra_descs;
@@ -306,6 +322,7 @@ static int compress_common(ndzip_hip_compressor *c, const void *d_in, int dims, 
     a.err = c->err;
     a.stream = c->stream;
     a.num_cus = c->num_cus;
+    a.device = c->device;
     a.aligned = is_aligned(c->dtype, gg, d_in);
     if (verbose()) fprintf(stderr, "[ndzip-hip] compress: %u hypercubes, %llu border elements\n", gg.nhc,
             static_cast<unsigned long long>(bg.count));
@@ -384,8 +401,9 @@ int ndzip_hip_decompressor_create(int dtype, int dims, void *hip_stream, ndzip_h
     *out = nullptr;
     if (!valid_dtype(dtype)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid dtype");
     if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");
-    if (int s = ensure_device(nullptr)) return s;
-    auto *d = new ndzip_hip_decompressor{dtype, dims, static_cast<hipStream_t>(hip_stream), nullptr};
+    int xcds = 1;
+    if (int s = ensure_device(nullptr, nullptr, &xcds)) return s;
+    auto *d = new ndzip_hip_decompressor{dtype, dims, static_cast<hipStream_t>(hip_stream), nullptr, xcds};
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&d->err), sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(d->err, 0, sizeof(uint32_t), d->stream);
     if (e != hipSuccess) {
@@ -416,6 +434,7 @@ static int decompress_common(ndzip_hip_decompressor *d, const uint32_t *d_header
     a.stream = d->stream;
     a.aligned = is_aligned(d->dtype, gg, d_out);
     a.body_words = body_words;
+    a.num_xcds = d->num_xcds;
     if (verbose()) fprintf(stderr, "[ndzip-hip] decompress: %u hypercubes, %llu border elements\n", gg.nhc,
             static_cast<unsigned long long>(border_count(gg)));
     if (gg.nhc > 0) {
@@ -505,9 +524,13 @@ int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, cons
     event_pair ev;
     const bool timed = kernel_ns != nullptr || verbose();
     int status = NDZIP_HIP_OK;
-    do {
+    // A look-back that timed out (a predecessor tile's workgroup did not publish within the poll budget: the persistent grid
+    // was not fully resident, e.g. because another process held part of the GPU) spoils this launch only: the input is still on
+    // the device, so the launch is repeated ONCE before the caller sees NDZIP_HIP_ERR_DEVICE_FAULT.  (The device-pointer entry
+    // points cannot do that -- they never synchronise; their callers see the fault in ndzip_hip_compressor_check().)
+    for (int attempt = 0;; ++attempt) {
         if (timed) {
-            if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
+            if (!ev.start && (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess)) {
                 status = fail(NDZIP_HIP_ERR_RUNTIME, "hipEventCreate failed");
                 break;
             }
@@ -523,8 +546,15 @@ int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, cons
             if (kernel_ns) *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
             if (verbose()) fprintf(stderr, "[ndzip-hip][profile] total kernel time %.3fms\n", static_cast<double>(ms));
         }
-        status = ndzip_hip_compressor_check(c);
-    } while (false);
+        uint32_t bits = 0;
+        status = check_error_word(c->err, c->stream, &bits);
+        if (status == NDZIP_HIP_ERR_DEVICE_FAULT && bits == err_lookback_timeout && attempt == 0) {
+            if (verbose()) fprintf(stderr, "[ndzip-hip] scan look-back timeout: relaunching once\n");
+            continue;
+        }
+        if (status == NDZIP_HIP_ERR_DEVICE_FAULT && attempt > 0) status = fail(status, g_last_error + " -- again after one relaunch");
+        break;
+    }
     ndzip_hip_compressor_destroy(c);
     if (status) return status;
     uint32_t len = 0;
@@ -602,6 +632,7 @@ struct offload_slot {
     int job = 0;  // 0 idle, 1 compress, 2 decompress
     void *host_out = nullptr;
     uint32_t words = 0;  // decompress: words consumed, known at submit
+    uint32_t extent[3] = {0, 0, 0};  // compress: the job's extent (for the relaunch after a look-back timeout)
 };
 }  // namespace
 
@@ -723,6 +754,7 @@ int ndzip_hip_offloader_submit_compress(ndzip_hip_offloader *o, int slot, const 
     HIP_TRY(hipMemcpyAsync(s->h_len, s->d_len, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     s->job = 1;
     s->host_out = stream;
+    for (int d = 0; d < 3; ++d) s->extent[d] = d < o->dims ? extent[d] : 1u;
     return NDZIP_HIP_OK;
 }
 
@@ -778,7 +810,13 @@ int ndzip_hip_offloader_submit_decompress(ndzip_hip_offloader *o, int slot, cons
     return NDZIP_HIP_OK;
 }
 
-int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, uint64_t *kernel_ns) {
+}  // extern "C"
+
+namespace {
+// `dest` != nullptr: a compress job's stream goes there (room for `dest_capacity_words`) instead of to the buffer named at
+// submit time -- the copy happens here, when the exact length is known, so a caller that packs streams back to back
+// (ndzip_hip_chunked_compress) names the final place only now.
+int offloader_wait_impl(ndzip_hip_offloader *o, int slot, void *dest, uint64_t dest_capacity_words, uint32_t *words, uint64_t *kernel_ns) {
     offload_slot *s = nullptr;
     if (int st = slot_of(o, slot, &s, false)) return st;
     const int job = s->job;
@@ -795,12 +833,23 @@ int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, 
         fprintf(stderr, "[ndzip-hip][profile] slot %d total kernel time %.3fms\n", slot, static_cast<double>(ms));
     }
     if (job == 1) {
-        if (int st = ndzip_hip_compressor_check(s->comp)) return st;
+        uint32_t bits = 0;
+        int st = check_error_word(s->comp->err, s->comp->stream, &bits);
+        if (st == NDZIP_HIP_ERR_DEVICE_FAULT && bits == err_lookback_timeout) {
+            // the array is still in the slot's device buffer: one relaunch (see ndzip_hip_offload_compress)
+            if (verbose()) fprintf(stderr, "[ndzip-hip] slot %d: scan look-back timeout: relaunching once\n", slot);
+            if (int e = ndzip_hip_compressor_compress(s->comp, s->d_array, o->dims, s->extent, s->d_stream, s->d_len)) return e;
+            HIP_TRY(hipMemcpyAsync(s->h_len, s->d_len, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+            st = check_error_word(s->comp->err, s->comp->stream, &bits);
+            if (st == NDZIP_HIP_ERR_DEVICE_FAULT) st = fail(st, g_last_error + " -- again after one relaunch");
+        }
+        if (st) return st;
         const uint32_t len = *s->h_len;
         const size_t wb = word_bytes(o->dtype);
         if (static_cast<size_t>(len) * wb > o->stream_bytes) return fail(NDZIP_HIP_ERR_DEVICE_FAULT, "stream length exceeds bound");
+        if (dest && len > dest_capacity_words) return fail(NDZIP_HIP_ERR_CAPACITY, "stream buffer too small for the compressed streams");
         if (len) {
-            HIP_TRY(hipMemcpyAsync(s->host_out, s->d_stream, static_cast<size_t>(len) * wb, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(dest ? dest : s->host_out, s->d_stream, static_cast<size_t>(len) * wb, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
         }
         if (words) *words = len;
@@ -809,6 +858,13 @@ int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, 
         if (words) *words = s->words;
     }
     return NDZIP_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, uint64_t *kernel_ns) {
+    return offloader_wait_impl(o, slot, nullptr, 0, words, kernel_ns);
 }
 
 // ---- arrays beyond the format's 32-bit counts: one stream per slab of dimension 0 -----------------------------------------
@@ -903,21 +959,15 @@ int ndzip_hip_chunked_compress(int dtype, int dims, const uint64_t *extent, uint
     const size_t wb = word_bytes(dtype);
     const char *in = static_cast<const char *>(data);
     char *out = static_cast<char *>(streams);
-    uint64_t written = 0, reserved = 0, ns_total = 0;
-    // A slab's stream goes to a provisional place (after the bounds of everything still in flight) and is moved up to its
-    // final place when it retires and its predecessors' true lengths are known.
-    struct job {
-        uint64_t provisional;  // word offset the stream was produced at
-        uint64_t bound;
-    } jobs[slots] = {};
+    uint64_t written = 0, ns_total = 0;
+    // Slabs retire in order, and a slab's stream leaves the device only when it retires -- with its exact length known and its
+    // predecessors' streams already in place: it is copied straight behind them (no provisional placement, no host-side move).
     int status = NDZIP_HIP_OK;
     auto retire = [&](uint64_t k) {
         uint32_t words = 0;
         uint64_t ns = 0;
-        const int st = ndzip_hip_offloader_wait(o, static_cast<int>(k % slots), &words, &ns);
+        const int st = offloader_wait_impl(o, static_cast<int>(k % slots), out + written * wb, capacity_words - written, &words, &ns);
         if (st) return st;
-        const job &j = jobs[k % slots];
-        if (j.provisional != written && words) memmove(out + written * wb, out + j.provisional * wb, static_cast<size_t>(words) * wb);
         written += words;
         ns_total += ns;
         return static_cast<int>(NDZIP_HIP_OK);
@@ -927,16 +977,7 @@ int ndzip_hip_chunked_compress(int dtype, int dims, const uint64_t *extent, uint
         if (status) break;
         uint32_t e[3];
         chunk_extent(p, dims, extent, k, e);
-        const uint64_t bound = length_bound(dtype, make_geom(dims, e));
-        // everything still in flight was reserved behind `written` at submit time; keep reserving behind the furthest
-        if (reserved < written) reserved = written;
-        if (reserved + bound > capacity_words) {
-            status = fail(NDZIP_HIP_ERR_CAPACITY, "stream buffer smaller than ndzip_hip_chunked_plan's length bound");
-            break;
-        }
-        jobs[k % slots] = {reserved, bound};
-        status = ndzip_hip_offloader_submit_compress(o, static_cast<int>(k % slots), e, in + k * p.rows_per_chunk * p.rest * wb, out + reserved * wb);
-        reserved += bound;
+        status = ndzip_hip_offloader_submit_compress(o, static_cast<int>(k % slots), e, in + k * p.rows_per_chunk * p.rest * wb, out);
     }
     for (uint64_t k = p.num_chunks > slots ? p.num_chunks - slots : 0; k < p.num_chunks && !status; ++k) status = retire(k);
     ndzip_hip_offloader_destroy(o);

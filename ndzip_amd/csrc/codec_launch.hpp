@@ -30,6 +30,7 @@ struct compress_args {
     uint32_t *err;         // device error word (sticky)
     hipStream_t stream;
     int num_cus;
+    int device;            // HIP device ordinal the launch goes to (keys the per-device occupancy cache)
     bool aligned;          // 16-byte aligned base and row strides
 };
 
@@ -44,6 +45,7 @@ struct decompress_args {
     hipStream_t stream;
     bool aligned;
     uint32_t body_words;      // words of `body` the caller vouches for (hypercube runs + border); 0xffffffff = unknown
+    int num_xcds;             // accelerator complexes (separate L2s) workgroups are dealt to round-robin: hipDeviceAttributeNumberOfXccs
 };
 
 // hypercubes per compress / decompress workgroup for (T, dims)
@@ -69,6 +71,11 @@ enum debug_stage : int {
     debug_transpose32_generic = 5,
     debug_wave_scan = 6,          // in: n uint32 (n a multiple of 64)   -> out: per wavefront of 64, the inclusive prefix sums;
                                   //                                         out[n + w] = the wave sum of wavefront w
+    debug_lookback_scan = 7,      // in: n uint32 tile lengths           -> out: their n exclusive prefix sums, out[n] = the total,
+                                  //     out[n + 1] = the error word; `hc` = workgroups of the persistent grid (0: as many as the
+                                  //     production launch would use).  The production ticket / publish / look-back / release
+                                  //     functions on their own, two launches on one scratch (epoch 1 and 2): the device-wide
+                                  //     scan at tile counts no array that fits a test can reach
 };
 
 template<typename T>

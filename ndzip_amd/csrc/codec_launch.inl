@@ -82,11 +82,13 @@ NDZIP_DEV uint32_t tile_of_ticket(uint32_t ticket, uint32_t cls, uint32_t num_cl
 // that are too small, so its stream is garbage although every write stayed in bounds -- the stream length is then
 // poisoned to 0 (shorter than any valid stream: every consumer of the length fails loudly, ndzip_hip_stream_words and
 // the decompress entry points reject it) for callers that never call ndzip_hip_compressor_check().  Ordering without a
-// cache write-back: work-item 0 of a workgroup is the only one that sets the error word (atomic), stores the stream length
-// (write-through agent-scope store) and increments `done`; it waits for its own memory operations to complete in between
-// (an agent-scope release fence here = a write-back of the XCD's whole L2, ~3.5 us per workgroup: MI355X guide).
+// cache write-back: work-item 0 of a workgroup is the only one that sets the error word, stores the stream length and
+// increments `done`, and the first two are RETURNING agent-scope atomics (gfx950_lds.hpp: *_performed) -- they have been
+// performed where all XCDs meet before the `done` increment is issued, so the workgroup that reads `done == grid - 1` and then
+// the error word (agent-scope load) sees both, and its poison store comes after every length store.  (An agent-scope release
+// fence here = a write-back of the XCD's whole L2, ~3.5 us per workgroup: MI355X guide.)
 NDZIP_DEV void store_stream_length(uint32_t *out_len, uint32_t words) {
-    if (out_len) __hip_atomic_store(out_len, words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (out_len) exchange_performed(out_len, words);
 }
 NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid, uint32_t *err, uint32_t *out_len) {
     if (tid != 0) return;
@@ -227,7 +229,7 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
         base -= lookback_lanes;
         ++hop;
     }
-    if (timed_out && lane == 0) atomicOr(err, 1u);
+    if (timed_out && lane == 0) fetch_or_performed(err, 1u);
     if (lane == 0) desc_store(desc.p + tile, desc_tag(desc.epoch, 2u) | (exclusive + aggregate));
     return exclusive;
 }
@@ -627,7 +629,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
 template<typename T, int Dims, bool Aligned>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads))
 decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restrict__ header_base_ptr, const typename word_of<T>::type *__restrict__ body,
-        typename word_of<T>::type *__restrict__ out, const grid_geom gg, uint32_t *err, const uint32_t body_words) {
+        typename word_of<T>::type *__restrict__ out, const grid_geom gg, uint32_t *err, const uint32_t body_words, const uint32_t num_xcds) {
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -640,16 +642,18 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
     char *cube = smem + grp * C::cube_stride;
     uint32_t *xchg = reinterpret_cast<uint32_t *>(smem + K * C::cube_stride + L::zero_bytes) + grp * (C::xchg_bytes / 4);
 
-    // Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8), each with its own L2.  Giving every XCD a
+    // Workgroups are dealt to the XCDs round-robin (block b runs on XCD b % num_xcds; num_xcds = hipDeviceAttributeNumberOfXccs
+    // of the device the launch goes to: 8 in SPX mode, fewer in a partitioned device), each with its own L2.  Giving every XCD a
     // CONTIGUOUS range of tiles makes neighbouring tiles -- whose hypercube rows share cache lines when the rows are not
     // line-aligned, and whose streams are adjacent -- meet in one L2 instead of leaving two partially written copies of a
-    // line in two L2s (510x511x509 f32: 0.313 -> 0.239 ms; aligned grids unchanged).
+    // line in two L2s (510x511x509 f32: 0.313 -> 0.239 ms; aligned grids unchanged).  The mapping is a permutation of the
+    // tiles whatever num_xcds is: a wrong count costs locality, never correctness.
     // For f64 with aligned rows (every hypercube row is whole lines) the plain order measured 2-4 % faster: used there.
     constexpr bool xcd_ranges = sizeof(W) == 4 || !Aligned;
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
-    const uint32_t per_xcd = (ntiles + 7) / 8;
-    const uint32_t tile = xcd_ranges ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
-    const uint32_t hc = tile < ntiles ? tile * K + grp : gg.nhc;  // (grid rounded up to a multiple of 8: surplus blocks idle)
+    const uint32_t per_xcd = (ntiles + num_xcds - 1) / num_xcds;
+    const uint32_t tile = xcd_ranges ? (blockIdx.x % num_xcds) * per_xcd + blockIdx.x / num_xcds : blockIdx.x;
+    const uint32_t hc = tile < ntiles ? tile * K + grp : gg.nhc;  // (grid rounded up to a multiple of num_xcds: surplus blocks idle)
     const bool active = hc < gg.nhc;
     uint32_t begin = 0, len = 0;
     if (active) {
@@ -696,7 +700,9 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
         }
     }
     __syncthreads();
-    decode_hypercube<T, Dims, Aligned>(out, gg, active ? hc_origin<Dims>(gg, hc) : 0, active && len != 0, cube,
+    // (a hypercube whose header entry was rejected decodes the all-zero run staged above: its region of `out` is written as
+    // zeros -- deterministic, never what the caller's buffer happened to hold -- and the error word says so)
+    decode_hypercube<T, Dims, Aligned>(out, gg, active ? hc_origin<Dims>(gg, hc) : 0, active, cube,
             mis * static_cast<uint32_t>(sizeof(W)), xchg, t);
 }
 
@@ -834,6 +840,55 @@ __global__ void debug_wave_scan_kernel(const uint32_t *in, uint32_t *out, uint32
     if (lane == 0) out[n + i / 64] = total;
 }
 
+// The device-wide scan on its own: the production ticket scheme, aggregate publish, look-back (preloaded window one iteration
+// later, exactly the compress kernels' order: publish tile i, then resolve tile i-1) and release, over `ntiles` given lengths
+// instead of encoded hypercubes.  One wavefront per workgroup -- the look-back is wavefront 0's job in the compress kernels too.
+// (Reference counterpart of what this checks: hierarchical_inclusive_scan at 2^24 elements, src/test/cuda_bits_test.cu:94-114.)
+__global__ void __launch_bounds__(64)
+debug_lookback_kernel(const uint32_t *__restrict__ lengths, uint32_t *__restrict__ exclusive, uint32_t ntiles, tile_desc *desc_base,
+        uint32_t *tickets, const uint32_t num_classes, uint32_t *total, uint32_t *err, const uint32_t epoch) {
+    const desc_ref desc{desc_base, epoch};
+    __shared__ uint32_t slot[2];
+    const int lane = static_cast<int>(threadIdx.x);
+    const uint32_t cls = blockIdx.x % num_classes;
+    uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
+    if (lane == 0) slot[0] = atomicAdd(ticket_counter, 1u);
+    __syncthreads();
+    uint32_t tile = tile_of_ticket(slot[0], cls, num_classes);
+    bool have_prev = false;
+    uint32_t prev_tile = 0, prev_aggregate = 0;
+    for (;;) {
+        const bool have_cur = tile < ntiles;
+        if (!have_cur && !have_prev) break;
+        lookback_windows window{};
+        if (have_prev) lookback_issue(desc, prev_tile, lane, window);
+        uint32_t aggregate = 0;
+        if (have_cur) {
+            aggregate = lengths[tile];
+            if (lane == 0) publish_aggregate(desc, tile, aggregate);
+        }
+        if (have_prev) {
+            const uint32_t prefix = resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
+            if (lane == 0) {
+                exclusive[prev_tile] = prefix;
+                if (prev_tile == ntiles - 1) store_stream_length(total, prefix + prev_aggregate);
+            }
+        }
+        uint32_t next_tile = tile;
+        if (have_cur) {
+            if (lane == 0) slot[1] = atomicAdd(ticket_counter, 1u);
+            __syncthreads();
+            next_tile = tile_of_ticket(slot[1], cls, num_classes);
+            __syncthreads();
+        }
+        have_prev = have_cur;
+        prev_tile = tile;
+        prev_aggregate = aggregate;
+        tile = next_tile;
+    }
+    release_tickets(tickets, num_classes, lane, err, total);
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------------------
 
 // persistent grid, fully resident: workgroups per CU bounded by the occupancy query and by what the LDS alone admits
@@ -850,6 +905,23 @@ hipError_t persistent_blocks_per_cu(Kernel kernel, int threads, uint32_t smem_by
     *out = n < 1 ? 1 : n;
     return hipSuccess;
 }
+
+// Workgroups per CU of one kernel, asked of the runtime once PER DEVICE (a process that drives several GPUs launches the same
+// kernel on parts with different CU / LDS configurations; ordinals beyond the table are simply asked every time).
+struct occupancy_cache {
+    static constexpr int max_devices = 64;
+    int blocks_per_cu[max_devices] = {};
+    template<typename Kernel>
+    hipError_t get(int device, Kernel kernel, int threads, uint32_t smem_bytes, int *out) {
+        if (device >= 0 && device < max_devices && blocks_per_cu[device] != 0) {
+            *out = blocks_per_cu[device];
+            return hipSuccess;
+        }
+        const hipError_t e = persistent_blocks_per_cu(kernel, threads, smem_bytes, out);
+        if (e == hipSuccess && device >= 0 && device < max_devices) blocks_per_cu[device] = *out;  // (racing threads store the same value)
+        return e;
+    }
+};
 
 // Scratch layout (fixed, whatever the extent): [16 x u64 reserved (lab builds: phase counters)][ticket counters, one per 128 B][1 line:
 // workgroups done][descriptors].  Nothing is cleared per launch: descriptors carry the launch epoch, the kernel zeroes the
@@ -874,11 +946,9 @@ hipError_t launch_compress_profile(const compress_args &a) {
         // f64: 256 work-items per hypercube, one hypercube per tile (codec_kernels_wide.hpp)
         using C = wide_cfg<W>;
         auto kernel = compress_kernel_wide<W, Dims, Aligned>;
-        static int blocks_per_cu = 0;
-        if (blocks_per_cu == 0) {
-            hipError_t e = persistent_blocks_per_cu(kernel, C::threads, C::smem_bytes, &blocks_per_cu);
-            if (e != hipSuccess) return e;
-        }
+        static occupancy_cache cache;
+        int blocks_per_cu = 0;
+        if (hipError_t e = cache.get(a.device, kernel, C::threads, C::smem_bytes, &blocks_per_cu); e != hipSuccess) return e;
         return launch_persistent<decltype(kernel), W>(kernel, C::threads, C::smem_bytes, blocks_per_cu, a.gg.nhc, a);
     } else {
         // f32: 128 work-items per hypercube, two hypercubes per tile; in 3D with an even hypercube count along x every tile
@@ -891,12 +961,9 @@ hipError_t launch_compress_profile(const compress_args &a) {
             paired = a.gg.g[2] % 2 == 0;
             if (paired) kernel = compress_kernel_db<T, Dims, Aligned, true>;
         }
-        static int blocks_per_cu_of[2] = {0, 0};
-        int &blocks_per_cu = blocks_per_cu_of[paired ? 1 : 0];
-        if (blocks_per_cu == 0) {
-            hipError_t e = persistent_blocks_per_cu(kernel, C::threads, C::smem_bytes, &blocks_per_cu);
-            if (e != hipSuccess) return e;
-        }
+        static occupancy_cache cache_of[2];
+        int blocks_per_cu = 0;
+        if (hipError_t e = cache_of[paired ? 1 : 0].get(a.device, kernel, C::threads, C::smem_bytes, &blocks_per_cu); e != hipSuccess) return e;
         return launch_persistent<decltype(kernel), W>(kernel, C::threads, C::smem_bytes, blocks_per_cu, ntiles, a);
     }
 }
@@ -907,9 +974,10 @@ hipError_t launch_decompress_profile(const decompress_args &a) {
     using W = typename C::W;
     const uint32_t ntiles = (a.gg.nhc + C::K - 1) / C::K;
     if (ntiles == 0) return hipSuccess;
-    const uint32_t grid = (ntiles + 7) / 8 * 8;  // see the kernel: tiles are dealt to XCDs in contiguous ranges
+    const uint32_t xcds = a.num_xcds > 0 ? static_cast<uint32_t>(a.num_xcds) : 1u;
+    const uint32_t grid = (ntiles + xcds - 1) / xcds * xcds;  // see the kernel: tiles are dealt to XCDs in contiguous ranges
     hipLaunchKernelGGL((decompress_kernel<T, Dims, Aligned>), dim3(grid), dim3(C::threads), C::smem_bytes, a.stream,
-            a.header, a.header_base, static_cast<const W *>(a.body), static_cast<W *>(a.out), a.gg, a.err, a.body_words);
+            a.header, a.header_base, static_cast<const W *>(a.body), static_cast<W *>(a.out), a.gg, a.err, a.body_words, xcds);
     return hipGetLastError();
 }
 
@@ -950,7 +1018,7 @@ int compress_hcs_per_group<T_>(int) {
 
 template<>
 uint32_t compress_num_tiles<T_>(int, uint32_t nhc) {
-    return nhc;  // descriptors for the finest tiling any kernel variant uses (one hypercube per tile)
+    return (nhc + tile_cfg<T_, 1>::K - 1) / tile_cfg<T_, 1>::K;  // one descriptor per tile: K hypercubes (2 for 32-bit, 1 for 64-bit profiles)
 }
 
 template<>
@@ -971,6 +1039,32 @@ hipError_t launch_debug_stage<T_>(int stage, int dims, const grid_geom &gg, uint
         hipLaunchKernelGGL(debug_wave_scan_kernel, dim3(n / 64), dim3(64), 0, stream, static_cast<const uint32_t *>(in),
                 static_cast<uint32_t *>(out), n);
         return hipGetLastError();
+    }
+    if (stage == debug_lookback_scan) {
+        // in: n lengths; out: n prefixes, the total, the error word.  Scratch of its own (zeroed once), two launches on it.
+        if (n == 0) return hipErrorInvalidValue;
+        int dev = 0, cus = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        uint32_t grid = hc ? hc : static_cast<uint32_t>(cus) * 4u;  // (4 one-wavefront workgroups per CU are resident on any part)
+        if (grid > n) grid = n;
+        const uint32_t num_classes = grid < ticket_classes ? 1u : ticket_classes;
+        tile_desc *scratch = nullptr;
+        const size_t entries = static_cast<size_t>(n) + scratch_extra_descs;
+        e = hipMalloc(reinterpret_cast<void **>(&scratch), entries * sizeof(tile_desc));
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(scratch, 0, entries * sizeof(tile_desc), stream);
+        uint32_t *o = static_cast<uint32_t *>(out);
+        if (e == hipSuccess) e = hipMemsetAsync(o + n, 0, 2 * sizeof(uint32_t), stream);
+        for (uint32_t epoch = 1; epoch <= 2 && e == hipSuccess; ++epoch) {
+            hipLaunchKernelGGL(debug_lookback_kernel, dim3(grid), dim3(64), 0, stream, static_cast<const uint32_t *>(in), o, n,
+                    scratch + scratch_extra_descs, reinterpret_cast<uint32_t *>(scratch + 16), num_classes, o + n, o + n + 1, epoch);
+            e = hipGetLastError();
+        }
+        const hipError_t s = hipStreamSynchronize(stream);
+        (void) hipFree(scratch);
+        return e != hipSuccess ? e : s;
     }
     if (stage == debug_transpose32 || stage == debug_transpose32_generic) {
         if (n == 0) return hipSuccess;

@@ -34,25 +34,28 @@ def pytest_sessionstart(session):
     from ndzip_amd import build as hipbuild
     from tests.wavesim import build as simbuild
 
-    try:  # a fresh checkout: cross-compile the product library the C-ABI / adaptor / CLI tests load (what __graft_entry__.build() does)
+    # A fresh checkout: cross-compile the product library the C-ABI / adaptor / CLI tests load (what __graft_entry__.build()
+    # does) and the checkers (the C oracle and, where /root/reference exists, the real serial reference, oracle/_ref).  A build
+    # that fails ends the session here, with the compiler's message -- not later, as a missing library inside some test.
+    try:
         hipbuild.build()
         hipbuild.build_test_variants()
     except Exception as e:
-        print(f"product build failed: {e}")
-    try:  # the checkers: the C oracle and, where /root/reference exists, the real serial reference (oracle/_ref)
+        pytest.exit(f"product build failed:\n{e}", returncode=2)
+    try:
         from oracle import oracle
 
         oracle.build(ref=True)
     except Exception as e:
-        print(f"oracle build failed: {e}")
+        pytest.exit(f"oracle build failed:\n{e}", returncode=2)
 
     jobs = [dict(), dict(variant="spin0", defines=("NDZIP_LOOKBACK_SPIN_LIMIT=0",)), dict(variant="asan", extra_flags=simbuild.ASAN_FLAGS),
             dict(variant="ldsprof", defines=("WAVESIM_LDSPROF",), kernel_flags=simbuild.LDSPROF_FLAGS)]
     try:
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(lambda kw: simbuild.build(**kw), jobs))
-    except Exception as e:  # the tests that need a library rebuild it and fail with the compiler's message
-        print(f"wavesim prebuild failed: {e}")
+    except Exception as e:
+        pytest.exit(f"functional-model build failed:\n{e}", returncode=2)
 
 
 def pytest_collection_modifyitems(config, items):

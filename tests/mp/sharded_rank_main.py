@@ -1,0 +1,91 @@
+"""One rank of the N-rank parity run of ndzip_amd.sharded.ShardedCodec, launched by torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        tests/mp/sharded_rank_main.py --backend nccl --out DIR --case float32:96,64,48 [--case ...]
+
+--backend nccl   one GPU per rank (cuda:LOCAL_RANK), RCCL collectives on device tensors: tests/test_hip_sharded_rccl.py (-m gpu)
+--backend gloo --model   host tensors, the kernels' functional model (tests/wavesim): the rehearsal of the very same script in
+                 the GPU-less container, tests/test_sharded_cpu.py
+
+Per case every rank compresses its slab three times on one ShardedCodec (handle reuse: descriptor epochs, ticket reset, header
+buffers), decompresses it, and writes rank<r>_case<i>.npz = its header_global, body, base and round-trip verdict; the test
+process assembles the stream from those files and compares it with the oracle's."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 47
+
+
+def case_data(case):
+    """(dtype, extent, full array) of a `dtype:e0,e1,...` case (the test process builds the same array for the oracle)."""
+    from ndzip_amd.synth import synth_numpy
+
+    name, ext = case.split(":")
+    dtype = np.dtype(name).type
+    extent = tuple(int(x) for x in ext.split(","))
+    return dtype, extent, synth_numpy(extent, dtype, seed=SEED, noise_mask=0xFF)
+
+
+def main():
+    import contextlib
+
+    import torch
+    import torch.distributed as dist
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", choices=["nccl", "gloo"], required=True)
+    ap.add_argument("--model", action="store_true", help="kernels on the functional model, host tensors (CPU rehearsal)")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--case", action="append", required=True)
+    ap.add_argument("--async-header-gather", action="store_true")
+    args = ap.parse_args()
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+
+    from ndzip_amd.sharded import ShardedCodec
+
+    if args.model:
+        from tests.wavesim import sim
+
+        device = torch.device("cpu")
+        scope = sim.active()
+    else:
+        assert torch.cuda.is_available() and torch.cuda.device_count() > local_rank, "one visible GPU per rank"
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+        scope = contextlib.nullcontext()
+    kw = {"device_id": device} if args.backend == "nccl" else {}
+    dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+    with scope:
+        for i, case in enumerate(args.case):
+            dtype, extent, full = case_data(case)
+            wdt = np.uint32 if np.dtype(dtype).itemsize == 4 else np.uint64
+            codec = ShardedCodec(dtype, extent, rank, world, device, async_header_gather=args.async_header_gather)
+            sh = codec.shard
+            slab = torch.from_numpy(np.ascontiguousarray(full[sh.start0: sh.start0 + sh.extent[0]])).to(device)
+            out = torch.zeros_like(slab)
+            for _ in range(3):
+                codec.compress(slab)
+                codec.decompress(out)
+            codec.check()
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            n = int(codec.body_len.cpu().numpy().view(np.uint32)[0])
+            np.savez(os.path.join(args.out, f"rank{rank}_case{i}.npz"),
+                     header=codec.header_global.cpu().numpy().view(np.uint32).copy(),
+                     body=codec.body[:n].cpu().numpy().view(wdt).copy(),
+                     base=int(codec.base32.cpu().numpy().view(np.uint32)[0]),
+                     roundtrip=bool(np.array_equal(out.cpu().numpy().reshape(-1).view(wdt), slab.cpu().numpy().reshape(-1).view(wdt))))
+            dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,10 +127,35 @@ def test_main_produces_the_contract_line_on_the_model(monkeypatch, capsys, argv,
     assert set(d["per_gpu"]) == {"both": {"compress_GBps", "compress_frac_of_hbm_peak", "decompress_GBps", "decompress_frac_of_hbm_peak"},
                                  "compress": {"compress_GBps", "compress_frac_of_hbm_peak"},
                                  "decompress": {"decompress_GBps", "decompress_frac_of_hbm_peak"}}[mode]
+    assert "traffic" in r and r["traffic"] is None  # (no counters were ever taken on a 32^3 model run: null, not a stale number)
     cb = d["cpu_baseline"]
-    assert set(cb) >= {"value", "unit", "cores", "kind", "sample"} and cb["kind"] in ("reference", "port")
+    assert set(cb) >= {"value", "unit", "cores", "kind", "sample", "why_kind"} and cb["kind"] in ("reference", "port")
+    assert cb["why_kind"].startswith("kind=" + cb["kind"])
     if oracle.have_ref():
         assert cb["kind"] == "reference" and "cpu_reference_serial_cfg1" in d and d["cpu_reference_serial_cfg1"]["cores"] == 1
+
+
+def test_traffic_is_reported_only_for_counters_taken_on_these_kernels(monkeypatch, capsys, tmp_path):
+    """profiles/traffic.json entries carry the fingerprint of the device-code sources they were measured on; an entry of other
+    kernels (the committed round-1 one, say) leaves roofline.traffic null and says why."""
+    import shutil
+
+    from ndzip_amd.build import kernels_fingerprint
+    from tests.wavesim import sim
+
+    root = tmp_path / "root"
+    (root / "profiles").mkdir(parents=True)
+    monkeypatch.setattr(bench, "Accelerator", _HostAccelerator)
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    shutil.copytree(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "oracle"), root / "oracle", symlinks=True)
+    for kernels, want in (("somebody-else", None), (kernels_fingerprint(), 4242)):
+        with open(root / "profiles" / "traffic.json", "w") as f:
+            json.dump({"float32-32x32x32": {"kernels": kernels, "compress_hbm_bytes_per_launch": 4242, "source": "test"}}, f)
+        with sim.active():
+            bench.main(["--shape", "32,32,32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+        d = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+        assert d["roofline"]["traffic"] == want
+        assert ("none:" in d["roofline"].get("traffic_source", "")) == (want is None)
 
 
 def _bench_rank(rank, world, port, out_dir):

@@ -25,7 +25,7 @@ def run(cli, *args, stdin=b""):
 def test_help_lists_the_reference_options(cli):
     r = run(cli, "--help")
     text = (r.stdout + r.stderr).decode()
-    for opt in ("--decompress", "--array-size", "--data-type", "--target_str", "--threads", "--input", "--output", "--no-mmap"):
+    for opt in ("--decompress", "--array-size", "--data-type", "--target_str", "--threads", "--input", "--output", "--no-mmap", "--mmap"):
         assert opt in text
     assert "Compress or decompress binary float dump" in text
 
@@ -104,7 +104,7 @@ def model_cli(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("io", ["mmap", "no-mmap", "pipes"])
+@pytest.mark.parametrize("io", ["mmap", "no-mmap", "default", "pipes"])
 @pytest.mark.parametrize("dtype,shape,chunks", [(np.float32, (32, 32, 48), 4), (np.float64, (70, 130), 3), (np.float32, (4096 * 2 + 9,), 5)])
 def test_file_roundtrip_matches_the_reference_format(model_cli, tmp_path, io, dtype, shape, chunks):
     """compress.cc:17-86: the output is the plain concatenation of one stream per array; files are interchangeable with the
@@ -127,7 +127,7 @@ def test_file_roundtrip_matches_the_reference_format(model_cli, tmp_path, io, dt
         assert r2.returncode == 0, r2.stderr
         out = np.frombuffer(r2.stdout, dtype=dtype)
     else:
-        extra = ["--no-mmap"] if io == "no-mmap" else []
+        extra = ["--no-mmap"] if io == "no-mmap" else ["--mmap"] if io == "mmap" else []
         r = run(model_cli, "-n", *size, *t, "-i", str(src), "-o", str(ndz), *extra)
         assert r.returncode == 0, r.stderr
         assert b"ratio" in r.stderr and f"({chunks} chunks".encode() in r.stderr
@@ -147,10 +147,12 @@ def test_file_tool_rejects_partial_and_corrupt_input(model_cli, tmp_path):
     good = oracle.compress(np.ones(4096 * 2, dtype=np.float32))
     bad = good.copy()
     bad[0] = 0xFFFFFF00  # first header entry
-    for blob, msg in ((bad, b"corrupt stream header"), (good[:-3], b"longer than the given words")):
+    # (a truncated file: the buffered reader notices while refilling, the mapped one when the header is checked against the map)
+    for blob, msg, io in ((bad, b"corrupt stream header", []), (bad, b"corrupt stream header", ["--mmap"]),
+                          (good[:-3], b"truncated stream in input", []), (good[:-3], b"longer than the given words", ["--mmap"])):
         f = tmp_path / "bad.ndz"
         blob.tofile(f)
-        r = run(model_cli, "-d", "-n", "8192", "-i", str(f), "-o", str(tmp_path / "b.bin"))
+        r = run(model_cli, "-d", "-n", "8192", "-i", str(f), "-o", str(tmp_path / "b.bin"), *io)
         assert r.returncode != 0 and msg in r.stderr, r.stderr
 
 

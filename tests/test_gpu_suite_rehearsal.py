@@ -5,12 +5,16 @@ load, tools linked against the real library, process-isolated fault test) are sk
 This is not the GPU run and proves nothing about the MI355X."""
 import os
 import re
+import signal
 import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.timeout(1800)  # (above the child's own limit below; pytest.ini's 600 s would kill this test first and orphan the child)
 def test_gpu_suite_passes_on_the_functional_model():
     cmd = [sys.executable, "-m", "pytest", "tests", "-m", "gpu", "--rehearse-on-model", "-q", "-x", "-p", "no:cacheprovider"]
     try:  # (three test processes side by side when pytest-xdist is there: the full-size cases dominate and overlap)
@@ -19,7 +23,15 @@ def test_gpu_suite_passes_on_the_functional_model():
         cmd += ["-n", "3"]
     except ImportError:
         pass
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    # the child pytest (and its xdist workers) in a process group of its own, so that a timeout takes all of them down
+    proc = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=1500)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        pytest.fail("the rehearsal of the GPU suite did not finish in 1500 s\n" + out[-2000:])
+    r = subprocess.CompletedProcess(cmd, proc.returncode, out, err)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     m = re.search(r"(\d+) passed", tail)

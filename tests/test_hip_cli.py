@@ -33,7 +33,7 @@ def cli(hiplib):
 @pytest.mark.parametrize("slots,mmap", [(1, True), (3, True), (3, False)], ids=["1slot-mmap", "3slots-mmap", "3slots-stdio"])
 def test_cli_files_are_the_reference_tools_files(cli, cuda_device, tmp_path, case, slots, mmap):
     dtype, shape, n = case
-    io = [] if mmap else ["--no-mmap"]  # src/io/io.cc: mapped files by default, stdio with --no-mmap (and for pipes)
+    io = ["--mmap"] if mmap else ["--no-mmap"]  # src/io/io.cc: mapped files (here opt-in) or stdio (and for pipes)
     chunks = _chunks(dtype, shape, n)
     raw = tmp_path / "in.bin"
     np.concatenate([c.reshape(-1) for c in chunks]).tofile(raw)

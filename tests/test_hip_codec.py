@@ -221,3 +221,52 @@ def test_chunked_interface_for_arrays_beyond_the_format_limits(hiplib, cuda_devi
     assert len(got) == len(want) and np.array_equal(got, want)
     back, consumed = hip.chunked_decompress(want, dtype, shape, limit)
     assert consumed == len(want) and same_bits(back, data)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_corrupt_header_entries_decode_as_zeros_not_as_stale_memory(hiplib, cuda_device, profile):
+    """include/ndzip_hip.h: a header entry the format rules out makes the affected hypercubes (and, for the last entry, the
+    border) decode as ZEROS with the error word set.  The output buffer is pre-filled with a canary pattern: nothing of it may
+    survive, and the untouched hypercubes still decode bit-exactly.  (The reference trusts the header: cuda_codec.inl:628-652.)"""
+    import torch
+
+    import ndzip_amd
+
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 4 + 9,), 2: (side * 2 + 3, side * 2), 3: (side, side * 2 + 1, side * 2)}[dims]
+    data = random_unit_floats(shape, dtype, 19)
+    nhc = oracle.num_hypercubes(shape)
+    assert nhc == 4
+    wdt = torch.int32 if np.dtype(dtype) == np.float32 else torch.int64
+    canary = 0x5A5A5A5A if np.dtype(dtype) == np.float32 else 0x5A5A5A5A5A5A5A5A
+    n = int(np.prod(shape))
+    # per element: either the original value or exactly zero
+    for victim in (1, nhc - 1):
+        stream = oracle.compress(data).copy()
+        header = stream.view(np.uint32)
+        header[victim] = 0xFFFFFF00 if victim != nhc - 1 else header[victim] + 5 * (4096 + 128)
+        d_stream = torch.from_numpy(stream.view(np.int32 if stream.dtype == np.uint32 else np.int64)).to(cuda_device)
+        d_out = torch.full((n,), canary, dtype=wdt, device=cuda_device)
+        dec = ndzip_amd.make_hip_decompressor(dtype, dims, torch.cuda.current_stream().cuda_stream)
+        dec.decompress(d_stream, d_out, shape, stream_length_words=len(stream))
+        with pytest.raises(ndzip_amd.NdzipHipError, match="corrupt stream header"):
+            dec.check()
+        dec.close()
+        got = d_out.cpu().numpy().view(word_dtype(dtype)).reshape(shape)
+        want = np.ascontiguousarray(data).view(word_dtype(dtype))
+        assert not (got == canary).any(), "part of the output was left unwritten"
+        differs = got != want
+        assert (got[differs] == 0).all(), "a rejected region holds something other than zeros"
+        assert differs.any() and differs.sum() <= 2 * 4096 + oracle_border_elements(shape)
+        # a corrupt entry takes out its own hypercube and the one whose start it is; the first hypercube is never affected here
+        first = tuple(slice(0, side) for _ in range(dims))
+        assert not differs[first].any()
+
+
+def oracle_border_elements(shape):
+    side = SIDE[len(shape)]
+    inner = 1
+    for e in shape:
+        inner *= e // side * side
+    return int(np.prod(shape)) - inner

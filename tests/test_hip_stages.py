@@ -199,3 +199,48 @@ def test_wave_scan_and_sum(hiplib, cuda_device):
     want = np.concatenate([np.cumsum(x.reshape(-1, 64).astype(np.uint64), axis=1).astype(np.uint32).reshape(-1),
                            x.reshape(-1, 64).astype(np.uint64).sum(axis=1).astype(np.uint32)])
     assert np.array_equal(got, want)
+
+
+def _lookback_case(n, seed):
+    """n tile lengths as the compress kernels publish them (128 .. 8448 words per two-hypercube tile), scaled down when n is
+    large enough for their sum to leave 32 bits (the format's own limit: a stream has fewer than 2^32 words)."""
+    rng = np.random.default_rng(seed)
+    hi = min(8448, (2**32 - 1) // n)
+    x = rng.integers(min(128, hi), hi + 1, size=n, dtype=np.uint32)
+    x[: n // 7] = min(128, hi)  # a run of all-zero hypercubes: many equal small lengths in a row
+    return x
+
+
+def _check_lookback(cuda_device, n, grid, seed=5):
+    import torch
+
+    from ndzip_amd import hip
+
+    x = _lookback_case(n, seed)
+    d_out = torch.full((n + 2,), -1, dtype=torch.int32, device=cuda_device)
+    hip.debug_stage(7, np.float32, 1, None, grid, _t(x, cuda_device), d_out, None, n)
+    torch.cuda.synchronize()
+    got = _np(d_out, np.uint32)
+    incl = np.cumsum(x.astype(np.uint64))
+    assert incl[-1] < 2**32
+    assert got[n + 1] == 0, "look-back timeout"
+    assert got[n] == incl[-1], "total"
+    bad = np.flatnonzero(got[:n] != (incl - x).astype(np.uint32))
+    assert bad.size == 0, f"first wrong prefixes at tiles {bad[:8]}"
+
+
+@pytest.mark.parametrize("n,grid", [(1, 0), (63, 1), (4096, 1), (1 << 13, 16), (1 << 13, 17), (1 << 14, 0)])
+def test_lookback_scan_on_its_own(hiplib, cuda_device, n, grid):
+    """Stage 7: the production ticket / publish / look-back / release functions over n synthetic tile lengths against numpy's
+    cumulative sum -- with one workgroup (every look-back finds its predecessor's inclusive prefix), sixteen (one ticket class),
+    seventeen (sixteen classes) and the default grid; two launches on one scratch, so descriptor epochs and the ticket reset are
+    part of it.  The reference pins its device-wide scan the same way (src/test/cuda_bits_test.cu:94-114)."""
+    _check_lookback(cuda_device, n, grid)
+
+
+@pytest.mark.hardware_only
+@pytest.mark.parametrize("grid", [0, 16, 2048], ids=["default-grid", "16-workgroups", "2048-workgroups"])
+def test_lookback_scan_at_a_million_tiles(hiplib, cuda_device, grid):
+    """2^20 tiles -- twice the tile count of the largest configuration BASELINE names per GPU (16 GiB of float64: 524 288) and
+    far beyond what any array in this suite reaches -- through the same functions."""
+    _check_lookback(cuda_device, 1 << 20, grid, seed=6)

@@ -148,3 +148,38 @@ def test_sharded_codec_on_the_model_over_gloo(tmp_path, extent, dtype, world, as
         base += len(p["body"]) - s.border
     got = assemble_stream(dtype, extent, parts[0]["header"], [p["body"] for p in parts], [len(p["body"]) for p in parts], shards)
     assert len(got) == len(want) and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,async_gather", [(2, False), (3, True)])
+def test_rccl_parity_harness_rehearsed_over_gloo_on_the_model(tmp_path, world, async_gather):
+    """tests/test_hip_sharded_rccl.py's harness -- torch.distributed.run, tests/mp/sharded_rank_main.py, assembly, oracle
+    comparison -- with backend gloo and the kernels on the functional model: what runs on the first multi-GPU node is this,
+    with `--backend nccl` and one GPU per rank."""
+    from tests.test_hip_sharded_rccl import cases_for, check_against_oracle, launch_ranks
+    from tests.wavesim import build as simbuild
+
+    simbuild.build()  # once, before the ranks race for it
+    cases = cases_for(world)
+    launch_ranks(world, tmp_path, cases, "gloo", extra=["--model"] + (["--async-header-gather"] if async_gather else []), timeout=500)
+    check_against_oracle(world, tmp_path, cases)
+
+
+def test_cfg4_plan_for_eight_ranks():
+    """BASELINE configs[3] (3D float32 2048x1024x1024 over 8 GPUs): 8 slabs of 256 planes = 65 536 hypercubes each, a 256 KiB
+    header slice per rank, 2 MiB of header after the all-gather, no border; the per-rank sizes the ShardedCodec buffers take."""
+    import ndzip_amd
+
+    extent, world = (2048, 1024, 1024), 8
+    shards = plan_shards(extent, world)
+    assert [s.extent for s in shards] == [(256, 1024, 1024)] * 8 and [s.start0 for s in shards] == [256 * r for r in range(8)]
+    assert all(s.num_hypercubes == 65536 and s.border == 0 for s in shards)
+    assert [s.hc_begin for s in shards] == [65536 * r for r in range(8)] and shards[-1].hc_end == 524288
+    assert ndzip_amd.header_words(np.float32, 65536) * 4 == 256 << 10 and ndzip_amd.header_words(np.float32, 524288) * 4 == 2 << 20
+    # a rank's stream bound: its header slice + 65 536 x 4224 words -- and the whole array's bound is the sum (no rank needs more
+    # than a uint32 offset: 8 GiB in, at most 8.25 GiB out = 2.2e9 words < 2^32)
+    per_rank = ndzip_amd.compressed_length_bound(np.float32, shards[0].extent)
+    assert per_rank == 65536 + 65536 * 4224
+    assert ndzip_amd.compressed_length_bound(np.float32, extent) == 8 * per_rank < 2 ** 32
+    # cfg5 (3D float64 1024^3 x8, decompress-only): 128 planes = 32 768 hypercubes per rank
+    s5 = plan_shards((1024, 1024, 1024), 8)
+    assert all(s.extent == (128, 1024, 1024) and s.num_hypercubes == 32768 for s in s5)

@@ -321,3 +321,56 @@ def test_grid_larger_than_what_is_resident(resident, monkeypatch):
         got = sim.compress(data, cus=8, blocks_per_cu=3)
         assert len(got) == len(want) and np.array_equal(got, want)
         assert same_bits(sim.decompress(want, dtype, shape), data)
+
+
+def test_host_pointer_paths_relaunch_once_after_a_lookback_timeout(tmp_path):
+    """ndzip_hip_offload_compress / ndzip_hip_offloader_wait: a launch whose look-back timed out is repeated once (the input
+    is still on the device) before the caller sees NDZIP_HIP_ERR_DEVICE_FAULT.  Driven on the spin-limit-0 variant (any wait for
+    a predecessor is a timeout) in a subprocess with NDZIP_VERBOSE set, so that the relaunches can be counted on stderr: every
+    call either returns the oracle's stream or fails with "again after one relaunch", and never more than one relaunch per call."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "drive.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from ndzip_amd import hip\n"
+        "from ndzip_amd.synth import synth_numpy\n"
+        "from oracle import oracle\n"
+        "from tests.wavesim import sim\n"
+        "sim.load('spin0', defines=('NDZIP_LOOKBACK_SPIN_LIMIT=0',))\n"
+        "data = synth_numpy((16 * 6, 16 * 4, 16 * 4), np.float32, seed=1, noise_mask=0xFFFF)\n"
+        "want = oracle.compress(data)\n"
+        "ok = failed = 0\n"
+        "with sim.active(cus=4, blocks_per_cu=3, variant='spin0'):\n"
+        "    off = hip.make_hip_offloader(np.float32, 3)\n"
+        "    po = hip.HipPipelinedOffloader(np.float32, data.shape, slots=1)\n"
+        "    out = np.zeros(hip.compressed_length_bound(np.float32, data.shape), dtype=np.uint32)\n"
+        "    for i in range(6):\n"
+        "        print('CALL', file=sys.stderr, flush=True)\n"
+        "        try:\n"
+        "            if i % 2 == 0:\n"
+        "                got = off.compress(data)\n"
+        "            else:\n"
+        "                po.submit_compress(0, data, out)\n"
+        "                words, _ = po.wait(0)\n"
+        "                got = out[:words]\n"
+        "            assert np.array_equal(got, want)\n"
+        "            ok += 1\n"
+        "        except hip.NdzipHipError as e:\n"
+        "            assert 'again after one relaunch' in str(e), str(e)\n"
+        "            failed += 1\n"
+        "    po.close()\n"
+        "print('RESULT', ok, failed)\n")
+    env = dict(os.environ, NDZIP_VERBOSE="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ok, failed = (int(x) for x in r.stdout.split("RESULT")[1].split())
+    assert ok + failed == 6
+    calls = r.stderr.split("CALL\n")[1:]
+    assert len(calls) == 6
+    relaunches = [c.count("relaunching once") for c in calls]
+    assert max(relaunches) <= 1, "more than one relaunch in a call"
+    assert sum(relaunches) >= failed, "a call failed without having been relaunched"
+    assert sum(relaunches) > 0, "the spin-limit-0 variant never timed out in 6 calls"

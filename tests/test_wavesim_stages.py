@@ -150,3 +150,20 @@ def test_wave_scan_and_sum():
     want = np.concatenate([np.cumsum(x.reshape(-1, 64).astype(np.uint64), axis=1).astype(np.uint32).reshape(-1),
                            x.reshape(-1, 64).astype(np.uint64).sum(axis=1).astype(np.uint32)])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("schedule", ["", "reverse", "random:3"])
+@pytest.mark.parametrize("cus,n,grid", [(2, 1 << 12, 0), (5, 1 << 14, 0), (8, 1 << 15, 17), (2, 3000, 1)])
+def test_lookback_scan_on_its_own(schedule, cus, n, grid):
+    """Stage 7 (the production ticket / publish / look-back / release functions alone) over up to 2^15 synthetic tile lengths, with
+    the model's workgroups resumed forwards, backwards and in random order: prefix sums against numpy.  The GPU suite runs the
+    same stage at 2^20 tiles (tests/test_hip_stages.py)."""
+    from tests.test_hip_stages import _lookback_case
+
+    x = _lookback_case(n, 11)
+    out = np.full(n + 2, 0xFFFFFFFF, dtype=np.uint32)
+    with sim.active(cus=cus, blocks_per_cu=2, schedule=schedule):
+        hip.debug_stage(7, np.float32, 1, None, grid, _p(x), _p(out), None, n)
+    incl = np.cumsum(x.astype(np.uint64))
+    assert out[n + 1] == 0 and out[n] == incl[-1]
+    assert np.array_equal(out[:n], (incl - x).astype(np.uint32))

@@ -51,6 +51,9 @@ NDZIP_DEV int32_t opaque_vgpr(int32_t x) { return x; }
 
 NDZIP_DEV void wait_for_own_memory_operations() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
+NDZIP_DEV uint32_t exchange_performed(uint32_t *p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+NDZIP_DEV uint32_t fetch_or_performed(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+
 NDZIP_DEV vec16 global_load16_once(const void *p) {
     if (reinterpret_cast<uintptr_t>(p) % 16 != 0) {
         fprintf(stderr, "wavesim: global_load16_once at a misaligned address\n");

@@ -153,6 +153,8 @@ inline uint32_t __umulhi(uint32_t a, uint32_t b) { return static_cast<uint32_t>(
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_exchange(p, v, order, scope) __atomic_exchange_n((p), (v), (order))
+#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), (order))
 template<typename T>
 inline T atomicAdd(T *p, T v) {
     return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
@@ -201,7 +203,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount, hipDeviceAttributeNumberOfXccs };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 constexpr unsigned hipStreamNonBlocking = 1;
 constexpr unsigned hipHostMallocDefault = 0;
@@ -221,8 +223,12 @@ inline hipError_t hipGetDevice(int *d) {
     *d = 0;
     return hipSuccess;
 }
-inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) {
-    *v = wavesim_env_int("WAVESIM_CUS", 2);  // a persistent grid of 2 x (workgroups per CU) workgroups
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t what, int) {
+    if (what == hipDeviceAttributeNumberOfXccs) {
+        *v = wavesim_env_int("WAVESIM_XCDS", 8);  // (only an order of the decoder's tiles: any value must give the same bytes)
+    } else {
+        *v = wavesim_env_int("WAVESIM_CUS", 2);  // a persistent grid of 2 x (workgroups per CU) workgroups
+    }
     return hipSuccess;
 }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {

@@ -24,7 +24,10 @@ def short(name):
 def traffic_entry(counters, source):
     """HBM bytes per launch of the compress and decompress kernels from the FETCH_SIZE / WRITE_SIZE passes (KiB units; FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950)."""
-    entry, raw = {"source": source}, {}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ndzip_amd.build import kernels_fingerprint
+
+    entry, raw = {"source": source, "kernels": kernels_fingerprint()}, {}
     for kernel, which in (("compress_kernel", "compress"), ("decompress_kernel", "decompress")):
         hits = [v for k, v in counters.items() if k.startswith(kernel) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
         if not hits:
