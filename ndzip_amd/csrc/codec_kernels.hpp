@@ -300,6 +300,25 @@ NDZIP_DEV uint64_t local_offset(const grid_geom &gg, uint32_t k) {
     }
 }
 
+// local_offset<Dims>(gg, k0) of a work-item's first value k0 = t * (values per work-item access), as a wave-uniform element
+// offset (3D: the z-plane, which 64 consecutive work-items share whenever they cover at most 256 consecutive values) plus a
+// per-lane BYTE offset inside that plane / within the first rows.  The byte offset fits 32 bits for every legal array: an array
+// has at most 2^32 - 1 elements and at least `side` rows / planes, so 16 rows of a 3D plane are < 2^24 * 16 elements and 8 rows
+// of a 2D array < 2^26 * 8.
+template<int Dims, typename W>
+NDZIP_DEV void split_local_offset(const grid_geom &gg, uint32_t k0, uint64_t &uniform_elems, uint32_t &lane_bytes) {
+    if constexpr (Dims == 1) {
+        uniform_elems = 0;
+        lane_bytes = k0 * static_cast<uint32_t>(sizeof(W));
+    } else if constexpr (Dims == 2) {
+        uniform_elems = 0;
+        lane_bytes = ((k0 >> 6) * static_cast<uint32_t>(gg.stride[0]) + (k0 & 63u)) * static_cast<uint32_t>(sizeof(W));
+    } else {
+        uniform_elems = static_cast<uint64_t>(static_cast<uint32_t>(wave_uniform(static_cast<int>(k0 >> 8)))) * gg.stride[0];
+        lane_bytes = (((k0 >> 4) & 15u) * static_cast<uint32_t>(gg.stride[1]) + (k0 & 15u)) * static_cast<uint32_t>(sizeof(W));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // wave / group scans
 // ---------------------------------------------------------------------------------------------------------
@@ -390,11 +409,17 @@ NDZIP_DEV void load_hypercube_regs(const typename profile<T, Dims>::word *__rest
     // vector i of work-item t covers cube-local values k_i = (i*128 + t) * VE; 128*VE values are a whole number of
     // rows / planes, so the global offset is affine in i: one per-lane base plus a uniform step.  A vector never
     // crosses a hypercube row (VE divides the side length), so the same path serves unaligned rows.
-    const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
-    const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE);
+    // The address is split as in load_pair_regs: wave-uniform 64-bit base (hypercube origin, the z-plane this wavefront reads,
+    // i steps) + 32-bit per-lane byte offset inside a plane.
+    uint64_t plane;
+    uint32_t lane_bytes;
+    split_local_offset<Dims, W>(gg, static_cast<uint32_t>(t) * R::VE, plane, lane_bytes);
+    const char *base = reinterpret_cast<const char *>(in + origin + plane);
+    const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE) * sizeof(W);
     constexpr bool whole_lines = !(Dims == 3 && sizeof(W) == 4);  // (3D f32 rows are 64 bytes: half a line each)
+    const uint32_t off = lane_offset_here(lane_bytes);
 #pragma unroll
-    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned, whole_lines>(base + i * step);
+    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned, whole_lines>(scalar_pointer(base + i * step) + off);
 }
 
 // phase 0b: rotl1 and store to the padded LDS staging layout
@@ -443,12 +468,18 @@ NDZIP_DEV void load_pair_regs(const uint32_t *__restrict__ in, const grid_geom &
     using R = input_regs<uint32_t, true>;
     constexpr int first = Part == 1 ? Split : 0;
     constexpr int last = Part == 0 ? Split : R::NV;
+    // address = (wave-uniform 64-bit base: the tile, this wave pair's z-plane, the step) + (32-bit per-lane byte offset inside one
+    // z-plane: loop-invariant) -- so that the base arithmetic runs on the scalar unit and the load takes the SGPR-base + VGPR-offset
+    // form instead of a 64-bit per-lane pointer advanced by 64-bit VALU additions (a z-plane of a legal array is < 2^30 bytes:
+    // at most 2^32 - 1 elements over at least 16 planes)
     const uint32_t r0 = static_cast<uint32_t>(tid) >> 3, piece = static_cast<uint32_t>(tid) & 7u;
-    const uint32_t *base = in + pair_origin + static_cast<uint64_t>(r0 >> 4) * gg.stride[0] + static_cast<uint64_t>(r0 & 15u) * gg.stride[1]
-            + piece * 4u;
-    const uint64_t step = 2 * gg.stride[0];
+    const uint32_t zw = static_cast<uint32_t>(wave_uniform(static_cast<int>(r0 >> 4)));
+    const uint32_t lane_bytes = ((r0 & 15u) * static_cast<uint32_t>(gg.stride[1]) + piece * 4u) * 4u;
+    const char *base = reinterpret_cast<const char *>(in + pair_origin + static_cast<uint64_t>(zw) * gg.stride[0]);
+    const uint64_t step = 2 * gg.stride[0] * sizeof(uint32_t);
+    const uint32_t off = lane_offset_here(lane_bytes);
 #pragma unroll
-    for (int i = first; i < last; ++i) regs.v[i] = global_load16<true>(base + i * step);
+    for (int i = first; i < last; ++i) regs.v[i] = global_load16<true>(scalar_pointer(base + i * step) + off);
 }
 
 NDZIP_DEV void stage_pair_regs(const input_regs<uint32_t, true> &regs, char *cubes, uint32_t cube_stride, int tid) {
@@ -616,12 +647,8 @@ NDZIP_DEV void write_planes32(uint32_t *run, uint32_t run_word0, int t, uint32_t
             lds_write16(dst + 16 * i, v);
         }
     } else {
-        // (a running pointer, not a running index: one address increment per kept plane instead of index + shift-add + copy)
-        uint32_t *p = run + pos;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (planes[i] != 0) *p++ = planes[i];
-        }
+        // word-by-word compaction at a running LDS address, branch-free (gfx950_lds.hpp)
+        lds_append_nonzero(lds_address(run + pos), planes);
     }
 }
 

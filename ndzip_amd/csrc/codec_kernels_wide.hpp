@@ -56,10 +56,15 @@ NDZIP_DEV void load_regs(const W *__restrict__ in, const grid_geom &gg, uint64_t
     using R = input_regs<W>;
     constexpr int first = Part == 1 ? Split : 0;
     constexpr int last = Part == 0 ? Split : R::NV;
-    const W *base = in + origin + local_offset<Dims>(gg, static_cast<uint32_t>(t) * R::VE);
-    const uint64_t step = local_offset<Dims>(gg, threads * R::VE);
+    // (wave-uniform base + 32-bit per-lane byte offset: see load_hypercube_regs)
+    uint64_t plane;
+    uint32_t lane_bytes;
+    split_local_offset<Dims, W>(gg, static_cast<uint32_t>(t) * R::VE, plane, lane_bytes);
+    const char *base = reinterpret_cast<const char *>(in + origin + plane);
+    const uint64_t step = local_offset<Dims>(gg, threads * R::VE) * sizeof(W);
+    const uint32_t off = lane_offset_here(lane_bytes);
 #pragma unroll
-    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned>(base + i * step);
+    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned>(scalar_pointer(base + i * step) + off);
 }
 
 template<typename W>

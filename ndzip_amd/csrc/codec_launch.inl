@@ -72,6 +72,18 @@ NDZIP_DEV tile_desc desc_load(const tile_desc *p) {
 NDZIP_DEV void desc_store(tile_desc *p, tile_desc v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// One look-back window: lane l reads the descriptor of tile `nearest - l` (nearest = the window's first, i.e. highest, tile;
+// wave-uniform) -- "inclusive prefix 0" in front of tile 0, "outside the window" for lanes beyond it.  The address is a
+// wave-uniform base (the descriptor of tile nearest - 63, possibly in front of the array: it is only ever added to) plus a
+// per-lane byte offset, so that the load takes the SGPR-base form and no lane carries a 64-bit descriptor pointer around the loop.
+NDZIP_DEV tile_desc window_load(desc_ref desc, long long nearest, int lane) {
+    const long long idx = nearest - lane;
+    if (lane >= lookback_lanes) return desc_tag(desc.epoch, 3u);
+    if (idx < 0) return desc_tag(desc.epoch, 2u);
+    const char *base = reinterpret_cast<const char *>(desc.p) + (nearest - 63) * static_cast<long long>(sizeof(tile_desc));
+    const uint32_t off = lane_offset_here(static_cast<uint32_t>(63 - lane) * static_cast<uint32_t>(sizeof(tile_desc)));
+    return desc_load(reinterpret_cast<const tile_desc *>(scalar_pointer(base) + off));
+}
 
 // Ticket n of class c -> tile: plain interleave.  A class's tiles increase with its tickets.
 NDZIP_DEV uint32_t tile_of_ticket(uint32_t ticket, uint32_t cls, uint32_t num_classes) { return ticket * num_classes + cls; }
@@ -125,8 +137,7 @@ struct lookback_windows {
 NDZIP_DEV void lookback_issue(desc_ref desc, uint32_t tile, int lane, lookback_windows &w) {
 #pragma unroll
     for (int j = 0; j < lookback_prefetch; ++j) {
-        const long long idx = static_cast<long long>(tile) - 1 - lane - j * lookback_lanes;
-        w.d[j] = lane >= lookback_lanes ? desc_tag(desc.epoch, 3u) : idx >= 0 ? desc_load(desc.p + idx) : desc_tag(desc.epoch, 2u);
+        w.d[j] = window_load(desc, static_cast<long long>(tile) - 1 - j * lookback_lanes, lane);
     }
 }
 
@@ -186,10 +197,7 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
             }
         }
         for (;;) {
-            if (!use_preloaded) {
-                const long long idx = base - lane;
-                d = lane >= lookback_lanes ? desc_tag(desc.epoch, 3u) : idx >= 0 ? desc_load(desc.p + idx) : desc_tag(desc.epoch, 2u);
-            }
+            if (!use_preloaded) d = window_load(desc, base, lane);
             use_preloaded = false;
             const uint32_t status = desc_state(d, desc.epoch);
             const unsigned long long invalid = __ballot(status == 0);
@@ -252,30 +260,36 @@ NDZIP_DEV vec16 straddle(const vec16 &lo, const vec16 &hi) {
     return x;
 }
 
+// `d16`: wave-uniform (scalar_pointer); the per-lane part of every store address is the 32-bit 16 * v
 template<typename R, int S, int Threads>
-NDZIP_DEV void copy_vectors(const vec16 *__restrict__ a, vec16 *__restrict__ d16, uint32_t nvec, int tid) {
+NDZIP_DEV void copy_vectors(const vec16 *__restrict__ a, char *d16, uint32_t nvec, int tid) {
     const char *base = reinterpret_cast<const char *>(a);
     for (uint32_t v = tid; v < nvec; v += Threads) {
         const vec16 lo = lds_read16(R::ptr(base + 16 * v));
+        vec16 *d = reinterpret_cast<vec16 *>(d16 + 16u * v);
         if constexpr (S == 0) {
-            d16[v] = lo;
+            *d = lo;
         } else {
-            d16[v] = straddle<S>(lo, lds_read16(R::ptr(base + 16 * v + 16)));
+            *d = straddle<S>(lo, lds_read16(R::ptr(base + 16 * v + 16)));
         }
     }
 }
 
+// `dst` must be the same in every lane of a wavefront (a tile's place in the stream): it is kept in scalar registers, and the
+// alignment case analysis below is scalar code.
 template<typename W, int Threads>
-NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t n, int tid) {
+NDZIP_DEV void copy_out(const W *__restrict__ src, W *dst_any, uint32_t n, int tid) {
     constexpr uint32_t wpv = 16 / sizeof(W);
+    W *dst = scalar_pointer(dst_any);
     uint32_t lead = (wpv - static_cast<uint32_t>((reinterpret_cast<uintptr_t>(dst) / sizeof(W)) % wpv)) % wpv;
     if (lead > n) lead = n;
     using R = run_layout<W>;  // (`src` is the start of the run's region)
     const auto word = [&](uint32_t i) { return *R::ptr(src + i); };
-    if (static_cast<uint32_t>(tid) < lead) dst[tid] = word(tid);
+    const uint32_t t_bytes = static_cast<uint32_t>(tid) * static_cast<uint32_t>(sizeof(W));
+    if (static_cast<uint32_t>(tid) < lead) *reinterpret_cast<W *>(reinterpret_cast<char *>(dst) + lane_offset_here(t_bytes)) = word(tid);
     const uint32_t nvec = (n - lead) / wpv;
     const vec16 *a = reinterpret_cast<const vec16 *>(src);
-    vec16 *d16 = reinterpret_cast<vec16 *>(dst + lead);
+    char *d16 = reinterpret_cast<char *>(scalar_pointer(dst + lead));
     switch (lead * (sizeof(W) / 4)) {  // uint32 offset of the first vector inside its aligned LDS vector
         case 0: copy_vectors<R, 0, Threads>(a, d16, nvec, tid); break;
         case 1: copy_vectors<R, 1, Threads>(a, d16, nvec, tid); break;
@@ -283,7 +297,9 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *__restrict__ dst, uint32_t
         default: copy_vectors<R, 3, Threads>(a, d16, nvec, tid); break;
     }
     const uint32_t done = lead + nvec * wpv;
-    if (static_cast<uint32_t>(tid) < n - done) dst[done + tid] = word(done + tid);
+    if (static_cast<uint32_t>(tid) < n - done) {
+        *reinterpret_cast<W *>(reinterpret_cast<char *>(scalar_pointer(dst + done)) + lane_offset_here(t_bytes)) = word(done + tid);
+    }
 }
 
 // Tiles are handed out dynamically: `num_classes` ticket counters (class = blockIdx % num_classes, ticket n of class c
@@ -358,7 +374,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     // drift apart and the look-back waits); this is a quarter of an iteration.
     if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
-    uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
+    // (tickets are the same in every lane: as scalars, so that the tile's origin -- two magic-number divisions and 64-bit
+    // multiply-adds -- is computed once on the scalar unit, not per lane)
+    uint32_t tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 2]))), cls, num_classes);
 
     static_assert(!Paired || (Dims == 3 && sizeof(W) == 4 && K == 2 && Aligned), "paired loads: 3D, 32-bit, aligned rows");
     input_regs<W, Aligned> pre;
@@ -399,7 +417,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         lookback_windows window{};
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
-        const uint32_t next_tile = have_cur ? tile_of_ticket(misc[NW + 1], cls, num_classes) : tile;
+        const uint32_t next_tile = have_cur ? tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 1]))), cls, num_classes) : tile;
         __builtin_amdgcn_sched_barrier(0);
         uint32_t next_hc = Paired ? next_tile * K : next_tile * K + grp;
         if (next_hc >= gg.nhc) next_hc = Paired ? gg.nhc - K : gg.nhc - 1;
@@ -474,7 +492,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         uint32_t ticket_after_next = 0;
         if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
-            const uint32_t prefix = misc[NW];
+            const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
             copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
             if (prev_active && t == 0) header[prev_hc] = prefix + prev_run_start + prev_my_len;  // offset_after(hc), common.hh:342-347
             // the last tile ends the body (store_stream_length, cuda_codec.inl:507-511)
@@ -540,7 +558,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     // tickets: see compress_kernel_db (first one in its own slot, every later one drawn behind the B3 before its consumer's B1)
     if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
-    uint32_t tile = tile_of_ticket(misc[NW + 2], cls, num_classes);
+    uint32_t tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 2]))), cls, num_classes);
 
     wide::input_regs<W> pre;
     wide::load_regs<W, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, tile < ntiles ? tile : ntiles - 1), t, pre);
@@ -560,7 +578,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         lookback_windows window{};  // (behind the staging: see compress_kernel_db)
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
-        const uint32_t next_tile = have_cur ? tile_of_ticket(misc[NW + 1], cls, num_classes) : tile;
+        const uint32_t next_tile = have_cur ? tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 1]))), cls, num_classes) : tile;
         __builtin_amdgcn_sched_barrier(0);
         const uint64_t next_origin = hc_origin<Dims>(gg, next_tile < ntiles ? next_tile : ntiles - 1);
         wide::load_regs<W, Dims, Aligned, 0, early_vectors>(in, gg, next_origin, t, pre);
@@ -604,7 +622,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         uint32_t ticket_after_next = 0;
         if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
-            const uint32_t prefix = misc[NW];
+            const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
             copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
             if (tid == 0) {
                 header[prev_tile] = prefix + prev_aggregate;  // offset_after(hc), common.hh:342-347
@@ -854,7 +872,7 @@ debug_lookback_kernel(const uint32_t *__restrict__ lengths, uint32_t *__restrict
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
     if (lane == 0) slot[0] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
-    uint32_t tile = tile_of_ticket(slot[0], cls, num_classes);
+    uint32_t tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(slot[0]))), cls, num_classes);
     bool have_prev = false;
     uint32_t prev_tile = 0, prev_aggregate = 0;
     for (;;) {
@@ -878,7 +896,7 @@ debug_lookback_kernel(const uint32_t *__restrict__ lengths, uint32_t *__restrict
         if (have_cur) {
             if (lane == 0) slot[1] = atomicAdd(ticket_counter, 1u);
             __syncthreads();
-            next_tile = tile_of_ticket(slot[1], cls, num_classes);
+            next_tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(slot[1]))), cls, num_classes);
             __syncthreads();
         }
         have_prev = have_cur;

@@ -23,15 +23,15 @@ struct alignas(16) vec16 {
 // only 8-byte aligned = 64.  A b128 access is served in groups of 16 consecutive lanes over sixteen 16-byte slots
 // (address / 16 mod 16); two lanes of a group in the same slot at different addresses double the group's cost.
 NDZIP_DEV vec16 lds_read16(const char *p) {
-    // The address goes through an empty volatile asm: it pins the order of the reads (hipcc otherwise hoists all 24
-    // stencil reads to the top and the kernel spills -- a scratch reload waits vmcnt(0), i.e. for every prefetch load
-    // in flight); the address-space cast keeps it a ds_ access.
+    // The address-space cast keeps it a ds_ access.  The address is NOT pinned through a register (rounds 1-2 passed it through an
+    // empty volatile asm to keep hipcc from hoisting all 24 stencil reads to the top): every pinned read needed its own
+    // address VGPR -- base + 16, base + 32 ... as 22 loop-invariant registers plus a v_mov per read -- where the unpinned read
+    // takes the constant in its offset field.  The order of the reads is held by the scheduling barriers between the groups of
+    // the stencil instead (compress_kernel_db<float, 3>: 157 -> 138 VGPRs, 758 -> 729 VALU instructions per iteration, no scratch).
     using lds_char = const __attribute__((address_space(3))) char;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     using lds_vec = const __attribute__((address_space(3))) u32x4;
-    uint32_t a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_char *) p));
-    asm volatile("" : "+v"(a));
-    const u32x4 q = *reinterpret_cast<lds_vec *>(static_cast<uintptr_t>(a));
+    const u32x4 q = *reinterpret_cast<lds_vec *>((lds_char *) p);
     vec16 v;
     v.w[0] = q.x;
     v.w[1] = q.y;
@@ -56,6 +56,31 @@ NDZIP_DEV char *lds_pointer(uint32_t address) {
 // tested on it becomes an s_cmp and a scalar branch instead of a v_cmp into a 64-bit lane mask that has to be kept (or spilled
 // and reloaded lane by lane) for as long as the condition is used.
 NDZIP_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// A wave-uniform 64-bit address, pinned in an SGPR pair: `pointer + (uint32_t) lane_offset` behind it is selected as the
+// SGPR-base + 32-bit-VGPR-offset form of global_load / global_store (one VGPR of address per lane instead of two, no 64-bit VALU
+// additions).  Without the pin LLVM re-associates (uniform + uniform) + lane into (uniform + lane) + uniform and is back at a
+// per-lane 64-bit pointer.
+// (`p` points to GLOBAL memory: the integer round trip would otherwise leave a generic pointer, i.e. flat_ accesses.)
+template<typename P>
+NDZIP_DEV P *scalar_pointer(P *p) {
+    // (v_readfirstlane folds away when the compiler can prove the value uniform, and makes the claim true where it cannot: an
+    // "s" operand fed from a VGPR is a back-end error, not a copy)
+    using global_p = __attribute__((address_space(1))) P;
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    unsigned long long a = static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))))
+            | (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)))) << 32);
+    asm("" : "+s"(a));
+    return (P *) reinterpret_cast<global_p *>(a);
+}
+
+// The 32-bit per-lane byte offset that goes with a scalar_pointer, re-materialised where it is used: instruction selection works
+// one basic block at a time, and only sees "SGPR pair + zero-extended 32-bit VGPR" (the SGPR-base addressing form) if the
+// zero-extension happens in the block of the access -- hoisted out of the loop it is just some 64-bit VGPR.  Emits nothing.
+NDZIP_DEV uint32_t lane_offset_here(uint32_t bytes) {
+    asm volatile("" : "+v"(bytes));
+    return bytes;
+}
 
 // Scheduling fence for a batch of 32 word reads from LDS: every LDS access above it is issued before any of `w` is used
 // below it.  Left alone, hipcc interleaves a dependent-address gather with the uses of its results (ds_read_b32 ;
@@ -119,5 +144,35 @@ NDZIP_DEV vec16 global_load16_once(const void *p) {
 // words are never looked at.  (The functional model checks exactly this contract under AddressSanitizer: at least one word of
 // the block inside the caller's buffer, junk substituted for the others.)
 NDZIP_DEV vec16 global_load16_block(const void *p) { return global_load16_once(p); }
+
+// Compaction of a chunk: the NON-ZERO words of w[0 .. 32) stored back to back from LDS byte address `a` on, in order; returns
+// the address behind the last one.  Per word: v_cmpx_ne_u32 (the lanes whose word is non-zero stay active), ds_write_b32,
+// v_add_u32 of the running address (under the same mask), s_mov_b64 exec back to the mask the sequence was entered with --
+// two VALU, one LDS and one SALU instruction and NO branch.  Written as `if (w[i]) *p++ = w[i]`, hipcc emits v_cmp, s_and_saveexec,
+// s_cbranch_execz, the store, the increment and s_or_b64 exec per word: 32 x (4 scalar instructions, one of them a branch, and a
+// saved 64-bit mask that lives in SGPRs) -- 250 of the 600 scalar-side instructions of a compress iteration, and enough SGPR
+// pressure that the kernel spilled 49 SGPRs to VGPR lanes (v_writelane / v_readlane in the loop).
+// The asm leaves EXEC as it found it at every statement boundary (the compiler does not know EXEC was touched and need not);
+// VCC is clobbered.  Hazards (gfx9 "manually inserted wait states"): none between a VALU write of EXEC and an LDS instruction
+// or a VALU instruction that is not DPP; a DPP instruction needs 5 wait states after v_cmpx -- the last v_cmpx is followed by
+// three instructions and s_nop 1 before control returns to compiled code.
+#define NDZIP_APPEND1(n) \
+    "v_cmpx_ne_u32_e32 vcc, 0, %[w" #n "]\n\tds_write_b32 %[a], %[w" #n "]\n\tv_add_u32_e32 %[a], 4, %[a]\n\ts_mov_b64 exec, %[full]\n\t"
+#define NDZIP_APPEND8 NDZIP_APPEND1(0) NDZIP_APPEND1(1) NDZIP_APPEND1(2) NDZIP_APPEND1(3) NDZIP_APPEND1(4) NDZIP_APPEND1(5) NDZIP_APPEND1(6) NDZIP_APPEND1(7)
+NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
+    unsigned long long full;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(full));
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        asm volatile(NDZIP_APPEND8 "s_nop 1"
+                     : [a] "+v"(a)
+                     : [w0] "v"(w[i]), [w1] "v"(w[i + 1]), [w2] "v"(w[i + 2]), [w3] "v"(w[i + 3]), [w4] "v"(w[i + 4]), [w5] "v"(w[i + 5]),
+                     [w6] "v"(w[i + 6]), [w7] "v"(w[i + 7]), [full] "s"(full)
+                     : "vcc", "memory");
+    }
+    return a;
+}
+#undef NDZIP_APPEND8
+#undef NDZIP_APPEND1
 
 }  // namespace ndzip_hip

@@ -43,6 +43,11 @@ NDZIP_DEV vec16 lds_read16(const char *p) {
 NDZIP_DEV uint32_t lds_address(const void *p) { return static_cast<uint32_t>(static_cast<const char *>(p) - smem); }
 NDZIP_DEV char *lds_pointer(uint32_t address) { return smem + address; }
 
+template<typename P>
+NDZIP_DEV P *scalar_pointer(P *p) { return p; }  // (register allocation only)
+
+NDZIP_DEV uint32_t lane_offset_here(uint32_t bytes) { return bytes; }
+
 NDZIP_DEV int wave_uniform(int x) { return x; }  // (the caller's claim; the value is the lane's own)
 
 NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction scheduling only)
@@ -95,6 +100,18 @@ NDZIP_DEV vec16 global_load16_block(const void *p) {
     v = *reinterpret_cast<const vec16 *>(p);
 #endif
     return v;
+}
+
+// the chunk compaction (product: an EXEC-masked store sequence in gfx950 assembly): non-zero words back to back from LDS byte
+// address `a` on, returns the address behind the last
+NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
+    for (int i = 0; i < 32; ++i) {
+        if (w[i] != 0) {
+            *reinterpret_cast<uint32_t *>(lds_pointer(a)) = w[i];
+            a += 4;
+        }
+    }
+    return a;
 }
 
 }  // namespace ndzip_hip
