@@ -418,8 +418,13 @@ NDZIP_DEV void load_hypercube_regs(const typename profile<T, Dims>::word *__rest
     const uint64_t step = local_offset<Dims>(gg, threads_per_hc * R::VE) * sizeof(W);
     constexpr bool whole_lines = !(Dims == 3 && sizeof(W) == 4);  // (3D f32 rows are 64 bytes: half a line each)
     const uint32_t off = lane_offset_here(lane_bytes);
+    // (a running scalar pointer: one 64-bit step in SGPRs instead of seven precomputed multiples of it)
+    const char *p = scalar_pointer(base + first * step);
 #pragma unroll
-    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned, whole_lines>(scalar_pointer(base + i * step) + off);
+    for (int i = first; i < last; ++i) {
+        regs.v[i] = global_load16<Aligned, whole_lines>(p + off);
+        if (i + 1 < last) p = scalar_pointer(p + step);
+    }
 }
 
 // phase 0b: rotl1 and store to the padded LDS staging layout
@@ -478,8 +483,12 @@ NDZIP_DEV void load_pair_regs(const uint32_t *__restrict__ in, const grid_geom &
     const char *base = reinterpret_cast<const char *>(in + pair_origin + static_cast<uint64_t>(zw) * gg.stride[0]);
     const uint64_t step = 2 * gg.stride[0] * sizeof(uint32_t);
     const uint32_t off = lane_offset_here(lane_bytes);
+    const char *p = scalar_pointer(base + first * step);  // (a running scalar pointer: see load_hypercube_regs)
 #pragma unroll
-    for (int i = first; i < last; ++i) regs.v[i] = global_load16<true>(scalar_pointer(base + i * step) + off);
+    for (int i = first; i < last; ++i) {
+        regs.v[i] = global_load16<true>(p + off);
+        if (i + 1 < last) p = scalar_pointer(p + step);
+    }
 }
 
 NDZIP_DEV void stage_pair_regs(const input_regs<uint32_t, true> &regs, char *cubes, uint32_t cube_stride, int tid) {

@@ -63,8 +63,12 @@ NDZIP_DEV void load_regs(const W *__restrict__ in, const grid_geom &gg, uint64_t
     const char *base = reinterpret_cast<const char *>(in + origin + plane);
     const uint64_t step = local_offset<Dims>(gg, threads * R::VE) * sizeof(W);
     const uint32_t off = lane_offset_here(lane_bytes);
+    const char *p = scalar_pointer(base + first * step);  // (a running scalar pointer: see load_hypercube_regs)
 #pragma unroll
-    for (int i = first; i < last; ++i) regs.v[i] = global_load16<Aligned>(scalar_pointer(base + i * step) + off);
+    for (int i = first; i < last; ++i) {
+        regs.v[i] = global_load16<Aligned>(p + off);
+        if (i + 1 < last) p = scalar_pointer(p + step);
+    }
 }
 
 template<typename W>

@@ -323,17 +323,22 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *dst_any, uint32_t n, int t
 // The encoded tile waits in REGISTERS (its 32 transposed planes per work-item), not in a second LDS buffer: the LDS
 // footprint stays at one staging region per hypercube (37 KiB per workgroup) and the register budget of 168 still
 // admits 3 workgroups = 12 wavefronts per CU (a second LDS buffer allowed only 2; measured 0.27 vs 0.32 ms).
-template<typename T, int Dims>
+template<typename T, int Dims, bool Paired>
 struct db_cfg {
     using C = tile_cfg<T, Dims>;
     static constexpr uint32_t smem_bytes = C::smem_bytes;
-    static constexpr int min_waves_per_simd = 3;
+    // Wavefronts per SIMD the register allocation is held to = workgroups per CU (a workgroup is one wavefront on each SIMD).
+    // 4 (128 VGPRs) where the kernel fits without scratch -- the paired 3D and the 2D instantiation, after round 3's register
+    // diet: 162 -> 134 VGPRs unconstrained, 128 with no spill; the LDS admits 4 x 37.5 KB -- and 3 (168 VGPRs) for the 1D and
+    // the unpaired 3D instantiation, which still spill one / two registers at 128: a scratch reload is a vector-memory load and
+    // waits for every prefetch load issued before it.
+    static constexpr int min_waves_per_simd = (Dims == 2 || Paired) ? 4 : 3;
 };
 
 // Paired: the two hypercubes of every tile are neighbours along x (3D, 32-bit, even hypercube count along x, aligned
 // rows): the tile is fetched as 256 rows of 128 bytes (load_pair_regs) instead of 2 x 256 rows of 64 bytes.
 template<typename T, int Dims, bool Aligned, bool Paired = false>
-__global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (db_cfg<T, Dims>::min_waves_per_simd))
+__global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (db_cfg<T, Dims, Paired>::min_waves_per_simd))
 compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
         typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
         uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t epoch) {
@@ -349,14 +354,13 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x);
-    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-    const int grp = wave / (threads_per_hc / 64), t = tid % threads_per_hc;
-    char *cube = smem + grp * C::cube_stride;                             // staging of this group's hypercube
+    const int grp0 = wave_uniform(tid >> 6) / (threads_per_hc / 64), t = tid % threads_per_hc;
+    char *cube = smem + grp0 * C::cube_stride;                            // staging of this group's hypercube
     uint32_t *tile_run = reinterpret_cast<uint32_t *>(smem);             // later: the K encoded runs, back to back
     char *zero_region = smem + K * C::cube_stride;
     // (the second hypercube's staging region sits 64 bytes = 4 sixteen-byte slots further round the banks than the first: so does
     // the zero block its out-of-cube neighbour reads go to -- the whole region is zero)
-    char *zero = zero_region + L::template zero_offset<Dims>() + grp * (C::cube_stride % 256);
+    char *zero = zero_region + L::template zero_offset<Dims>() + grp0 * (C::cube_stride % 256);
     uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
 
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
@@ -384,7 +388,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         const uint32_t first_tile = tile < ntiles ? tile : ntiles - 1;
         load_pair_regs<>(in, gg, hc_origin<Dims>(gg, first_tile * K), tid, pre);
     } else {
-        uint32_t first_hc = tile * K + grp;
+        uint32_t first_hc = tile * K + grp0;
         if (first_hc >= gg.nhc) first_hc = gg.nhc - 1;
         load_hypercube_regs<T, Dims, Aligned>(in, gg, hc_origin<Dims>(gg, first_hc), t, pre);
     }
@@ -399,6 +403,11 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     for (;;) {
         const bool have_cur = tile < ntiles;
         if (!have_cur && !have_prev) break;
+        // wave index, lane and the single-lane predicates of this iteration come from a fresh copy of the work-item id
+        // (gfx950_lds.hpp: fresh_copy): re-derived here, not carried round the loop as lane masks; addresses keep using `tid` / `t`
+        const int tid_i = fresh_copy(tid);
+        const int lane = tid_i & 63, wave = wave_uniform(tid_i >> 6), grp = wave / (threads_per_hc / 64);
+        const bool first_of_tile = tid_i == 0, first_of_hc = (tid_i & (threads_per_hc - 1)) == 0;
         const uint32_t hc = tile * K + grp;
         const bool active = have_cur && hc < gg.nhc;
         if (have_cur) {
@@ -449,7 +458,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
                 aggregate += len_g;
             }
             chunk_excl = ((wave & 1) ? misc[2 * grp] : 0u) + incl - count;
-            if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
+            if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
         // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
         // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
@@ -484,19 +493,19 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         // 0.207; this order 0.201-0.205.
         if (have_prev && wave == 0) {
             const uint32_t exclusive = resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
-            if (tid == 0) misc[NW] = exclusive;
+            if (first_of_tile) misc[NW] = exclusive;
         }
         __syncthreads();  // B3: previous tile's runs complete in LDS, its prefix known
         // the ticket the NEXT iteration reads behind its B1 (it needs one iff it has a tile); in flight during the copy-out
-        const bool draw = tid == 0 && next_tile < ntiles;
+        const bool draw = first_of_tile && next_tile < ntiles;
         uint32_t ticket_after_next = 0;
         if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
             const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
             copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
-            if (prev_active && t == 0) header[prev_hc] = prefix + prev_run_start + prev_my_len;  // offset_after(hc), common.hh:342-347
+            if (prev_active && first_of_hc) header[prev_hc] = prefix + prev_run_start + prev_my_len;  // offset_after(hc), common.hh:342-347
             // the last tile ends the body (store_stream_length, cuda_codec.inl:507-511)
-            if (tid == 0 && prev_tile == ntiles - 1) store_stream_length(out_len, len_extra + prefix + prev_aggregate);
+            if (first_of_tile && prev_tile == ntiles - 1) store_stream_length(out_len, len_extra + prefix + prev_aggregate);
         }
         if (draw) misc[NW + 1] = ticket_after_next;
         __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them; next ticket in LDS

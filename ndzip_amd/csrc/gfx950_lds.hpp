@@ -57,6 +57,15 @@ NDZIP_DEV char *lds_pointer(uint32_t address) {
 // and reloaded lane by lane) for as long as the condition is used.
 NDZIP_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// The same value, but nothing derived from it is loop-invariant as far as the optimiser can tell: predicates and wave indices
+// computed from this copy of the work-item id are re-derived (a compare, a v_readfirstlane + shift) where they are used instead of
+// being hoisted out of the persistent loop as 64-bit lane masks and scalars -- of which the compress kernels had more than the
+// SGPR file holds (34-47 spilled to VGPR lanes, read back with v_readlane + hazard nops every iteration).  Emits nothing.
+NDZIP_DEV int fresh_copy(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // A wave-uniform 64-bit address, pinned in an SGPR pair: `pointer + (uint32_t) lane_offset` behind it is selected as the
 // SGPR-base + 32-bit-VGPR-offset form of global_load / global_store (one VGPR of address per lane instead of two, no 64-bit VALU
 // additions).  Without the pin LLVM re-associates (uniform + uniform) + lane into (uniform + lane) + uniform and is back at a

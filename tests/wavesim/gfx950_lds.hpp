@@ -48,6 +48,8 @@ NDZIP_DEV P *scalar_pointer(P *p) { return p; }  // (register allocation only)
 
 NDZIP_DEV uint32_t lane_offset_here(uint32_t bytes) { return bytes; }
 
+NDZIP_DEV int fresh_copy(int x) { return x; }
+
 NDZIP_DEV int wave_uniform(int x) { return x; }  // (the caller's claim; the value is the lane's own)
 
 NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction scheduling only)
