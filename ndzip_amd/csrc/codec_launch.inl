@@ -327,12 +327,14 @@ template<typename T, int Dims, bool Paired>
 struct db_cfg {
     using C = tile_cfg<T, Dims>;
     static constexpr uint32_t smem_bytes = C::smem_bytes;
-    // Wavefronts per SIMD the register allocation is held to = workgroups per CU (a workgroup is one wavefront on each SIMD).
-    // 4 (128 VGPRs) where the kernel fits without scratch -- the paired 3D and the 2D instantiation, after round 3's register
-    // diet: 162 -> 134 VGPRs unconstrained, 128 with no spill; the LDS admits 4 x 37.5 KB -- and 3 (168 VGPRs) for the 1D and
-    // the unpaired 3D instantiation, which still spill one / two registers at 128: a scratch reload is a vector-memory load and
-    // waits for every prefetch load issued before it.
-    static constexpr int min_waves_per_simd = (Dims == 2 || Paired) ? 4 : 3;
+    // Wavefronts per SIMD the register allocation is held to = workgroups per CU (a workgroup is one wavefront on each SIMD):
+    // 4, i.e. 128 VGPRs -- every instantiation fits without scratch after round 3's register diet (the paired 3D kernel: 162 ->
+    // 134 VGPRs unconstrained, 128 with no spill), and the LDS admits 4 x 37.5 KB.  The 1D and the unpaired 3D instantiation
+    // get there by re-deriving their per-lane LDS addresses every iteration (rederive_lane_addresses: ~30 VALU instructions
+    // instead of a dozen loop-invariant VGPRs); the paired 3D and the 2D one fit as they are.  A kernel that spills is worse off
+    // than one at 3 wavefronts per SIMD: a scratch reload is a vector-memory load and waits for every prefetch load before it.
+    static constexpr bool rederive_lane_addresses = !(Dims == 2 || Paired);
+    static constexpr int min_waves_per_simd = 4;
 };
 
 // Paired: the two hypercubes of every tile are neighbours along x (3D, 32-bit, even hypercube count along x, aligned
@@ -408,13 +410,14 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         const int tid_i = fresh_copy(tid);
         const int lane = tid_i & 63, wave = wave_uniform(tid_i >> 6), grp = wave / (threads_per_hc / 64);
         const bool first_of_tile = tid_i == 0, first_of_hc = (tid_i & (threads_per_hc - 1)) == 0;
+        const int t_i = db_cfg<T, Dims, Paired>::rederive_lane_addresses ? (tid_i & (threads_per_hc - 1)) : t;
         const uint32_t hc = tile * K + grp;
         const bool active = have_cur && hc < gg.nhc;
         if (have_cur) {
             if constexpr (Paired) {
                 stage_pair_regs(pre, smem, C::cube_stride, tid);  // (an even hypercube count: both cubes of a tile exist)
             } else {
-                if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t);
+                if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t_i);
             }
         }
         // The previous tile's look-back window is read BEHIND the staging, not in front of it: the staging's wait for the
@@ -441,7 +444,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         W r[vals_per_thread];
         uint32_t head = 0, count = 0, incl = 0;
         if (have_cur) {
-            stencil_residuals<T, Dims>(cube, zero, t, r);
+            stencil_residuals<T, Dims>(cube, zero, t_i, r);
             head = chunk_head32(r);
             count = active ? static_cast<uint32_t>(__builtin_popcount(head)) : 0u;
             incl = wave_inclusive_scan(count, lane);
@@ -452,12 +455,15 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (have_cur) {
 #pragma unroll
             for (int g = 0; g < K; ++g) {
-                const uint32_t len_g = tile * K + g < gg.nhc ? P::head_words + misc[2 * g] + misc[2 * g + 1] : 0u;
+                // (wave totals as scalars: the tile's lengths, and with them the copy-out's case analysis, are scalar code, and
+                // the previous tile's aggregate / run start / length are carried round the loop in SGPRs, not VGPRs)
+                const uint32_t len_g = tile * K + g < gg.nhc ? P::head_words + static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * g])))
+                                + static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * g + 1]))) : 0u;
                 if (g < grp) run_start += len_g;
                 if (g == grp) my_len = len_g;
                 aggregate += len_g;
             }
-            chunk_excl = ((wave & 1) ? misc[2 * grp] : 0u) + incl - count;
+            chunk_excl = ((wave & 1) ? static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * grp]))) : 0u) + incl - count;
             if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
         // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
@@ -473,7 +479,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         if (have_prev) {
             // the previous tile's planes leave the registers: compact them into the (now free) staging region
             if (prev_active) {
-                write_planes32(tile_run + prev_run_start, prev_run_start, t, prev_head, prev_chunk_excl, planes);
+                write_planes32(tile_run + prev_run_start, prev_run_start, t_i, prev_head, prev_chunk_excl, planes);
             }
         }
         // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
@@ -529,22 +535,23 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
 // Same iteration structure as compress_kernel_db, one hypercube per tile: stage -> B1 -> early prefetch -> stencil -> B2 ->
 // publish -> late prefetch -> plane writes of the previous tile -> transpose of the current one -> look-back (wavefront 0)
 // -> B3 -> copy-out -> B4.  See codec_kernels_wide.hpp for the work-item mapping.
-template<typename W>
+template<typename W, int Dims>
 struct wide_cfg {
     static constexpr int threads = wide::threads;
     static constexpr int NW = threads / 64;
     static constexpr uint32_t smem_bytes = wide::layout<W>::cube_bytes + wide::layout<W>::zero_bytes + 64;
-    static constexpr int min_waves_per_simd = 3;
+    // 4 workgroups per CU (128 VGPRs, 4 x 36.4 KB of LDS): every instantiation fits without scratch (see db_cfg)
+    static constexpr int min_waves_per_simd = 4;
     static constexpr int early_vectors = wide::input_regs<W>::NV / 2;
 };
 
 template<typename W, int Dims, bool Aligned>
-__global__ void __launch_bounds__(wide_cfg<W>::threads, wide_cfg<W>::min_waves_per_simd)
+__global__ void __launch_bounds__((wide_cfg<W, Dims>::threads), (wide_cfg<W, Dims>::min_waves_per_simd))
 compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header, W *__restrict__ body,
         tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes, uint32_t *out_len, uint32_t len_extra, uint32_t *err,
         const uint32_t epoch) {
     const desc_ref desc{desc_base, epoch};
-    using C = wide_cfg<W>;
+    using C = wide_cfg<W, Dims>;
     using L = wide::layout<W>;
     using E = wide::coding<W>;
     constexpr int NW = C::NW;
@@ -552,7 +559,6 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = static_cast<int>(threadIdx.x), t = tid;
-    const int lane = tid & 63, wave = tid >> 6;  // (as a scalar -- wave_uniform -- this kernel gains nothing: measured on its ISA)
     char *cube = smem;
     uint32_t *run32 = reinterpret_cast<uint32_t *>(smem);  // later: the encoded run (f64: as uint32 halves of its words)
     char *zero_region = smem + L::cube_bytes;
@@ -583,7 +589,13 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     for (;;) {
         const bool have_cur = tile < ntiles;
         if (!have_cur && !have_prev) break;
-        if (have_cur) wide::stage_regs<W>(pre, cube, t);
+        // (wave index, lane and the single-lane predicate re-derived per iteration: see compress_kernel_db.  Here the LDS
+        // addresses of the staging, the stencil's row pointers and the coding's lane roles are re-derived from it too: ~30 VALU
+        // instructions per iteration instead of a dozen loop-invariant VGPRs, which is what fits the 1D and 2D kernel into 128)
+        const int tid_i = fresh_copy(tid);
+        const int lane = tid_i & 63, wave = wave_uniform(tid_i >> 6);
+        const bool first_of_tile = tid_i == 0;
+        if (have_cur) wide::stage_regs<W>(pre, cube, tid_i);
         lookback_windows window{};  // (behind the staging: see compress_kernel_db)
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
@@ -595,10 +607,10 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         W r[wide::vals];
         uint32_t head_a = 0, head_b = 0, count = 0, incl = 0;
         if (have_cur) {
-            wide::stencil<W, Dims>(cube, zero, t, r);
+            wide::stencil<W, Dims>(cube, zero, tid_i, r);
             count = E::head_and_count(r, head_a, head_b);
             // (the lanes of a chunk end up with the same inclusive value: only the first one feeds the scan)
-            incl = wave_inclusive_scan((t & (E::lanes_per_chunk - 1)) == 0 ? count : 0u, lane);
+            incl = wave_inclusive_scan((tid_i & (E::lanes_per_chunk - 1)) == 0 ? count : 0u, lane);
             if (lane == 63) misc[wave] = incl;
         }
         __syncthreads();  // B2: all stencil reads done (staging region reusable), wave totals known
@@ -607,33 +619,33 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
             aggregate = E::head_words;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                const uint32_t total = misc[w];
+                const uint32_t total = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[w])));  // (scalars: see compress_kernel_db)
                 aggregate += total;
                 if (w < wave) chunk_excl += total;
             }
             chunk_excl += incl - count;
-            if (tid == 0) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
+            if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         }
         __builtin_amdgcn_sched_barrier(0);
         wide::load_regs<W, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
         __builtin_amdgcn_sched_barrier(0);
         // the previous tile's planes leave the registers: compact them into the (now free) staging region
-        if (have_prev) E::write(prev_held, planes, run32, t);
+        if (have_prev) E::write(prev_held, planes, run32, tid_i);
         // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
-        if (have_cur) E::transpose(r, t, planes);
+        if (have_cur) E::transpose(r, tid_i, planes);
         __builtin_amdgcn_sched_barrier(0);
         if (have_prev && wave == 0) {
             const uint32_t exclusive = resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
-            if (tid == 0) misc[NW] = exclusive;
+            if (first_of_tile) misc[NW] = exclusive;
         }
         __syncthreads();  // B3: previous tile's run complete in LDS, its prefix known
-        const bool draw = tid == 0 && next_tile < ntiles;  // the ticket the next iteration reads behind its B1
+        const bool draw = first_of_tile && next_tile < ntiles;  // the ticket the next iteration reads behind its B1
         uint32_t ticket_after_next = 0;
         if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
             const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
             copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
-            if (tid == 0) {
+            if (first_of_tile) {
                 header[prev_tile] = prefix + prev_aggregate;  // offset_after(hc), common.hh:342-347
                 if (prev_tile == gg.nhc - 1) {
                     store_stream_length(out_len, len_extra + prefix + prev_aggregate);
@@ -647,7 +659,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         have_prev = have_cur;
         prev_tile = tile;
         prev_aggregate = aggregate;
-        prev_held = E::hold(t, head_a, head_b, E::head_words + chunk_excl);
+        prev_held = E::hold(tid_i, head_a, head_b, E::head_words + chunk_excl);
         tile = next_tile;
     }
     release_tickets(tickets, num_classes, tid, err, out_len);
@@ -971,7 +983,7 @@ hipError_t launch_compress_profile(const compress_args &a) {
     if (a.gg.nhc == 0) return hipSuccess;
     if constexpr (sizeof(T) == 8) {
         // f64: 256 work-items per hypercube, one hypercube per tile (codec_kernels_wide.hpp)
-        using C = wide_cfg<W>;
+        using C = wide_cfg<W, Dims>;
         auto kernel = compress_kernel_wide<W, Dims, Aligned>;
         static occupancy_cache cache;
         int blocks_per_cu = 0;

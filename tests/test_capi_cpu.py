@@ -104,13 +104,11 @@ def test_compress_and_decompress_kernels_do_not_spill():
     assert len(hot) == 25, sorted(res)  # f32 db (7: 6 + the paired 3D variant) + f64 wide (6) + decompress (12)
     for name, r in hot.items():
         assert r["scratch"] == 0, f"{name} spills {r['scratch']} bytes per lane"
-    f32_db = [v for k, v in hot.items() if "compress_kernel_dbIf" in k]
-    assert f32_db and all(r["occupancy"] >= 3 for r in f32_db)       # 3 workgroups of 4 wavefronts per CU at least
-    # the paired 3D kernel (the headline configuration's) and the 2D one run 4 workgroups per CU: 128 VGPRs, still no scratch
-    four = [v for k, v in hot.items() if "compress_kernel_dbIfLi3ELb1ELb1E" in k or "compress_kernel_dbIfLi2E" in k]
-    assert len(four) == 3 and all(r["occupancy"] == 4 and r["vgprs"] <= 128 for r in four), four
+    # every compress kernel runs 4 workgroups per CU: 128 VGPRs at most, still no scratch (round 2: 143-168 VGPRs, 3 per CU)
+    comp = {k: v for k, v in hot.items() if "decompress" not in k}
+    assert len(comp) == 13 and all(r["occupancy"] == 4 and r["vgprs"] <= 128 for r in comp.values()), comp
     # SGPR spills are VGPR-lane traffic (v_readlane + hazard nops) inside the persistent loop: 45-49 before round 3
-    assert all(r["sgpr_spill"] <= 20 for r in f32_db), f32_db
+    assert all(r["sgpr_spill"] <= 20 for r in comp.values()), comp
     dec = [v for k, v in hot.items() if "decompress_kernelIf" in k]
     assert dec and all(r["occupancy"] >= 5 for r in dec)                 # LDS admits 4 workgroups of 4 wavefronts per CU anyway
 
