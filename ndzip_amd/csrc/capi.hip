@@ -195,8 +195,8 @@ int check_error_word(uint32_t *d_err, hipStream_t stream, uint32_t *bits = nullp
     if (host != 0) {
         HIP_TRY(hipMemsetAsync(d_err, 0, sizeof host, stream));
         char buf[160];
-        snprintf(buf, sizeof buf, "device error word 0x%x (%s%s)", host, (host & 1u) ? "scan look-back timeout " : "",
-                (host & 2u) ? "corrupt stream header" : "");
+        snprintf(buf, sizeof buf, "device error word 0x%x (%s%s)", host, (host & err_lookback_timeout) ? "scan look-back timeout " : "",
+                (host & err_corrupt_header) ? "corrupt stream header" : "");
         return fail(NDZIP_HIP_ERR_DEVICE_FAULT, buf);
     }
     return NDZIP_HIP_OK;
