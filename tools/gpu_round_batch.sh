@@ -18,14 +18,20 @@ timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
 TRAFFIC_KEY=float32-512x512x512 timeout 900 bash tools/pmc.sh ${O}_rocprofv3_summary.txt
 TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_2d.txt --config 3
 # A/B of whatever variants were built on the CPU beforehand (tools/build_variant.sh, tools/build_history_variant.sh):
-#   plainloads = main without the nt input loads; dpp = before the ticket / window moves; r01 = the round-1 pipeline
-#   winpub = look-back window issued behind the aggregate publish; trlate = transposes behind the copy-out (f32 only)
-V="main"; for v in plainloads winpub trlate dpp r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
+#   r02 = the round-2 library (3 workgroups per CU, branchy plane compaction, per-lane pointers), r01 = the round-1 pipeline
+#   wg3 = HEAD held to 3 wavefronts per SIMD (f32 kernels): isolates what the 4th workgroup per CU buys
+#   plainloads = HEAD without the nt input loads
+V="main"; for v in wg3 r02 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
 (timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt
+(timeout 600 bash tools/ab.sh "$V" --config 1 2>&1) > ${O}_ab_variants_cfg1.txt
 #   linear64 = 64-bit encoded runs linear in LDS (the round-1 layout) instead of XOR-swizzled (f64 only)
-V64="main"; for v in linear64 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V64="$V64 $v"; done
+V64="main"; for v in r02 linear64 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V64="$V64 $v"; done
 (AB_MODE=both timeout 600 bash tools/ab.sh "$V64" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
 (AB_MODE=both timeout 600 bash tools/ab.sh "$V64" --shape 512,512,512 --dtype float64 2>&1) > ${O}_ab_variants_f64_3d.txt
+# per-phase cycle totals of the f32 compress iteration (lab build with phase timers; NDZIP_HIP_EXP=16)
+if [ -f ndzip_amd/_variants/timing.so ]; then
+  (NDZIP_HIP_EXP=16 timeout 300 python bench.py --lib $PWD/ndzip_amd/_variants/timing.so --steps 3 --warmup 1 --no-cpu-baseline --compress-only 2>&1 | tail -40) > ${O}_phase_timing.txt
+fi
 for i in 1 2 3 4 5 6; do
   echo "== run $i" >> ${O}_two_process_stress.txt
   HSA_ENABLE_IPC_MODE_LEGACY=0 CHECK_EACH=0 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
