@@ -501,6 +501,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             const uint32_t exclusive = resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
             if (first_of_tile) misc[NW] = exclusive;
         }
+        lds_append_complete();  // (the plane writes of write_planes32 are inline asm: the compiler's waitcnt insertion does not see them)
         __syncthreads();  // B3: previous tile's runs complete in LDS, its prefix known
         // the ticket the NEXT iteration reads behind its B1 (it needs one iff it has a tile); in flight during the copy-out
         const bool draw = first_of_tile && next_tile < ntiles;
@@ -784,6 +785,7 @@ debug_stage_kernel(int stage, const grid_geom gg, uint32_t hc, const typename wo
             for (int j = 0; j < 32; ++j) planes[j] = r[j];
             transpose32(planes);
             write_planes32(reinterpret_cast<uint32_t *>(cube), 0, t, head, (wave ? xchg[0] : 0u) + incl - count, planes);
+            lds_append_complete();
             __syncthreads();
             const uint32_t len = P::head_words + xchg[0] + xchg[1];
             const W *src = reinterpret_cast<const W *>(cube);

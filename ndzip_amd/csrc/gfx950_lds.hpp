@@ -184,4 +184,10 @@ NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
 #undef NDZIP_APPEND8
 #undef NDZIP_APPEND1
 
+// The stores of lds_append_nonzero are invisible to the compiler's s_waitcnt bookkeeping (inline asm is opaque to it): the
+// workgroup barrier behind which other wavefronts read the compacted run must be preceded by this explicit wait.  (In the builds
+// looked at the compiler had an lgkmcnt(0) of its own in front of that barrier -- for the chunk head it stores itself -- but
+// nothing obliges it to.)
+NDZIP_DEV void lds_append_complete() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 }  // namespace ndzip_hip

@@ -16,5 +16,6 @@ def test_lds_profile_of_a_small_grid():
     assert set(shares) == {"compress", "decompress"}
     # 3D f32 on the benchmark's synthetic data: conflicts are a fifth to a half of the LDS-array cycles (round-1 PMC: 35 / 40 %)
     assert 10 < shares["compress"] < 45 and 25 < shares["decompress"] < 55, shares
-    assert re.search(r"ds_write_b32\s+codec_kernels\.hpp:\d+", r.stdout), r.stdout  # the compaction writes, by source line
+    # the compaction writes, by source line (the model's stand-in for the EXEC-masked store sequence, called from write_planes32)
+    assert re.search(r"ds_write_b32\s+gfx950_lds\.hpp:\d+ <- codec_kernels\.hpp:\d+", r.stdout), r.stdout
     assert re.search(r"ds_read_b32\s+codec_kernels\.hpp:\d+", r.stdout)            # the decoder's gather

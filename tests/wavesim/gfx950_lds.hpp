@@ -116,4 +116,6 @@ NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
     return a;
 }
 
+NDZIP_DEV void lds_append_complete() {}
+
 }  // namespace ndzip_hip
