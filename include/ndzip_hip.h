@@ -155,7 +155,10 @@ NDZIP_HIP_API int ndzip_hip_decompressor_destroy(ndzip_hip_decompressor *d);
 /* offloader<T>::compress(data, data_size, stream, kernel_duration*)  (include/ndzip/offload.hh:16-19;
  * behaviour of cuda_offloader::do_compress, src/ndzip/cuda_codec.inl:669-714): H2D copy, device pipeline timed
  * with events (kernel_ns, may be NULL), D2H copy of length and stream.  `stream` must hold
- * compressed_length_bound words; *stream_length_words receives the return value of the reference call. */
+ * compressed_length_bound words; *stream_length_words receives the return value of the reference call.
+ * A launch whose device-wide scan timed out (NDZIP_HIP_ERR_DEVICE_FAULT, "scan look-back timeout": the persistent grid was not
+ * fully resident, e.g. on a GPU shared with another process) is repeated ONCE -- the array is still on the device -- before the
+ * error is returned; kernel_ns is that of the last launch. */
 NDZIP_HIP_API int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, const void *data, void *stream,
         uint32_t *stream_length_words, uint64_t *kernel_ns);
 
@@ -191,7 +194,8 @@ NDZIP_HIP_API int ndzip_hip_offloader_submit_decompress(ndzip_hip_offloader *o, 
         const void *stream, uint32_t stream_length_words, void *data);
 /* complete the job of `slot`: *words = the reference call's return value (stream length / words consumed), *kernel_ns =
  * device pipeline time by events (either may be NULL).  For a compress job the stream's D2H copy happens here, once the
- * length is known, on the slot's own stream. */
+ * length is known, on the slot's own stream; a compress job whose scan timed out is relaunched once from the slot's device copy of
+ * the array (see ndzip_hip_offload_compress) before NDZIP_HIP_ERR_DEVICE_FAULT is returned. */
 NDZIP_HIP_API int ndzip_hip_offloader_wait(ndzip_hip_offloader *o, int slot, uint32_t *words, uint64_t *kernel_ns);
 
 /* Words of the stream of an array of `extent` that starts at HOST pointer `stream`: header + last offset + border
