@@ -59,12 +59,15 @@ NDZIP_DEV uint32_t desc_state(tile_desc d, uint32_t epoch) {
 // uncached 8-byte agent-scope load, i.e. its own fabric transaction: measured on 512^3 f32, 256 per hop costs 45 us
 // more kernel time than 64 per hop, 1024 per hop 170 us more (profiles/) -- narrow windows win.
 constexpr int lookback_lanes = 64;
-// polls (with s_sleep between them, ~0.2 s in all) after which a look-back gives up and sets the error word; overridable only
-// so that the parity tests can force the give-up path
+// How long ONE look-back may wait for predecessors in all before it gives up and sets the error word: a TIME, in ticks of the
+// constant 100 MHz clock (s_memrealtime) -- 0.5 s -- not a number of polls, whose duration depends on the clocks and on what
+// else the memory system is doing.  A fully resident grid never comes near it (a predecessor publishes within an iteration, a
+// few microseconds); it is there for a grid that is NOT fully resident, e.g. on a GPU shared with another process.
+// Overridable only so that the parity tests can force the give-up path (0 = any wait for a predecessor is a time-out).
 #ifndef NDZIP_LOOKBACK_SPIN_LIMIT
-#define NDZIP_LOOKBACK_SPIN_LIMIT (1u << 20)
+#define NDZIP_LOOKBACK_SPIN_LIMIT 50000000ull
 #endif
-constexpr uint32_t spin_limit = NDZIP_LOOKBACK_SPIN_LIMIT;
+constexpr unsigned long long wait_budget_ticks = NDZIP_LOOKBACK_SPIN_LIMIT;
 
 NDZIP_DEV tile_desc desc_load(const tile_desc *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -183,7 +186,7 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
     uint32_t exclusive = 0;
     long long base = static_cast<long long>(tile) - 1;
     bool timed_out = false;
-    uint32_t spins = 0;
+    unsigned long long waited = 0;  // (lane 0's: ticks spent polling so far in this look-back)
     int hop = 0;
     for (;;) {
         bool found = false;
@@ -213,15 +216,20 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
             }
             if (wait_pos < 0) break;
             // the nearest missing predecessor: one lane polls it, then the window is read again
+            uint32_t expired = 0;
             if (lane == 0) {
                 const tile_desc *p = desc.p + (base - wait_pos);
-                while (desc_state(desc_load(p), desc.epoch) == 0 && spins < spin_limit) {
+                const unsigned long long t0 = realtime_ticks();
+                unsigned long long now = t0;
+                while (waited + (now - t0) < wait_budget_ticks && desc_state(desc_load(p), desc.epoch) == 0) {
                     __builtin_amdgcn_s_sleep(8);
-                    ++spins;
+                    now = realtime_ticks();
                 }
+                waited += now - t0;
+                expired = waited >= wait_budget_ticks ? 1u : 0u;
             }
-            spins = __shfl(spins, 0, 64);
-            if (spins >= spin_limit) {
+            expired = __shfl(expired, 0, 64);
+            if (expired) {
                 timed_out = true;  // (`found` / `lf` stay: an inclusive prefix in the window still bounds what may be summed)
                 break;
             }

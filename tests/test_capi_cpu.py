@@ -108,7 +108,7 @@ def test_compress_and_decompress_kernels_do_not_spill():
     comp = {k: v for k, v in hot.items() if "decompress" not in k}
     assert len(comp) == 13 and all(r["occupancy"] == 4 and r["vgprs"] <= 128 for r in comp.values()), comp
     # SGPR spills are VGPR-lane traffic (v_readlane + hazard nops) inside the persistent loop: 45-49 before round 3
-    assert all(r["sgpr_spill"] <= 20 for r in comp.values()), comp
+    assert all(r["sgpr_spill"] <= 24 for r in comp.values()), comp
     dec = [v for k, v in hot.items() if "decompress_kernelIf" in k]
     assert dec and all(r["occupancy"] >= 5 for r in dec)                 # LDS admits 4 workgroups of 4 wavefronts per CU anyway
 
