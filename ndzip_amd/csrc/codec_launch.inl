@@ -59,7 +59,7 @@ NDZIP_DEV uint32_t desc_state(tile_desc d, uint32_t epoch) {
 // uncached 8-byte agent-scope load, i.e. its own fabric transaction: measured on 512^3 f32, 256 per hop costs 45 us
 // more kernel time than 64 per hop, 1024 per hop 170 us more (profiles/) -- narrow windows win.
 constexpr int lookback_lanes = 64;
-// How long ONE look-back may wait for predecessors in all before it gives up and sets the error word: a TIME, in ticks of the
+// How long a look-back may wait for ONE missing predecessor before it gives up and sets the error word: a TIME, in ticks of the
 // constant 100 MHz clock (s_memrealtime) -- 0.5 s -- not a number of polls, whose duration depends on the clocks and on what
 // else the memory system is doing.  A fully resident grid never comes near it (a predecessor publishes within an iteration, a
 // few microseconds); it is there for a grid that is NOT fully resident, e.g. on a GPU shared with another process.
@@ -186,7 +186,6 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
     uint32_t exclusive = 0;
     long long base = static_cast<long long>(tile) - 1;
     bool timed_out = false;
-    unsigned long long waited = 0;  // (lane 0's: ticks spent polling so far in this look-back)
     int hop = 0;
     for (;;) {
         bool found = false;
@@ -219,14 +218,16 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
             uint32_t expired = 0;
             if (lane == 0) {
                 const tile_desc *p = desc.p + (base - wait_pos);
+                // (the budget applies to each wait for one predecessor: nothing is carried from wait to wait)
                 const unsigned long long t0 = realtime_ticks();
-                unsigned long long now = t0;
-                while (waited + (now - t0) < wait_budget_ticks && desc_state(desc_load(p), desc.epoch) == 0) {
+                expired = 1u;
+                while (realtime_ticks() - t0 < wait_budget_ticks) {
+                    if (desc_state(desc_load(p), desc.epoch) != 0) {
+                        expired = 0u;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(8);
-                    now = realtime_ticks();
                 }
-                waited += now - t0;
-                expired = waited >= wait_budget_ticks ? 1u : 0u;
             }
             expired = __shfl(expired, 0, 64);
             if (expired) {
