@@ -59,15 +59,16 @@ NDZIP_DEV uint32_t desc_state(tile_desc d, uint32_t epoch) {
 // uncached 8-byte agent-scope load, i.e. its own fabric transaction: measured on 512^3 f32, 256 per hop costs 45 us
 // more kernel time than 64 per hop, 1024 per hop 170 us more (profiles/) -- narrow windows win.
 constexpr int lookback_lanes = 64;
-// How long a look-back may wait for ONE missing predecessor before it gives up and sets the error word: a TIME, in ticks of the
-// constant 100 MHz clock (s_memrealtime) -- 0.5 s -- not a number of polls, whose duration depends on the clocks and on what
-// else the memory system is doing.  A fully resident grid never comes near it (a predecessor publishes within an iteration, a
-// few microseconds); it is there for a grid that is NOT fully resident, e.g. on a GPU shared with another process.
-// Overridable only so that the parity tests can force the give-up path (0 = any wait for a predecessor is a time-out).
+// Polls of a missing predecessor's descriptor after which a look-back gives up and sets the error word.  One poll is an
+// uncached agent-scope load round trip (>= 1 us under load) plus s_sleep 8, so 2^20 of them are a second or more -- against the
+// few microseconds a predecessor of a fully resident grid takes to publish.  A count, not a clock reading, on purpose: a time
+// budget (s_memrealtime) was tried in round 3 and its 64-bit scalars in the -- never executed -- waiting path cost the hot loop
+// registers: the compress kernels sit exactly at 128 VGPRs, and five of them went to scratch.  Overridable only so that the
+// parity tests can force the give-up path (0 = any wait for a predecessor is a time-out).
 #ifndef NDZIP_LOOKBACK_SPIN_LIMIT
-#define NDZIP_LOOKBACK_SPIN_LIMIT 50000000ull
+#define NDZIP_LOOKBACK_SPIN_LIMIT (1u << 20)
 #endif
-constexpr unsigned long long wait_budget_ticks = NDZIP_LOOKBACK_SPIN_LIMIT;
+constexpr uint32_t spin_limit = NDZIP_LOOKBACK_SPIN_LIMIT;
 
 NDZIP_DEV tile_desc desc_load(const tile_desc *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -186,6 +187,7 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
     uint32_t exclusive = 0;
     long long base = static_cast<long long>(tile) - 1;
     bool timed_out = false;
+    uint32_t spins = 0;
     int hop = 0;
     for (;;) {
         bool found = false;
@@ -215,22 +217,15 @@ NDZIP_DEV uint32_t resolve_exclusive_prefix_impl(desc_ref desc, uint32_t tile, u
             }
             if (wait_pos < 0) break;
             // the nearest missing predecessor: one lane polls it, then the window is read again
-            uint32_t expired = 0;
             if (lane == 0) {
                 const tile_desc *p = desc.p + (base - wait_pos);
-                // (the budget applies to each wait for one predecessor: nothing is carried from wait to wait)
-                const unsigned long long t0 = realtime_ticks();
-                expired = 1u;
-                while (realtime_ticks() - t0 < wait_budget_ticks) {
-                    if (desc_state(desc_load(p), desc.epoch) != 0) {
-                        expired = 0u;
-                        break;
-                    }
+                while (desc_state(desc_load(p), desc.epoch) == 0 && spins < spin_limit) {
                     __builtin_amdgcn_s_sleep(8);
+                    ++spins;
                 }
             }
-            expired = __shfl(expired, 0, 64);
-            if (expired) {
+            spins = __shfl(spins, 0, 64);
+            if (spins >= spin_limit) {
                 timed_out = true;  // (`found` / `lf` stay: an inclusive prefix in the window still bounds what may be summed)
                 break;
             }

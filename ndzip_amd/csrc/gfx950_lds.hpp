@@ -111,9 +111,6 @@ NDZIP_DEV int32_t opaque_vgpr(int32_t x) {
     return x;
 }
 
-// The constant-frequency (100 MHz) real-time counter, s_memrealtime: the time base of the look-back's give-up budget.
-NDZIP_DEV unsigned long long realtime_ticks() { return __builtin_amdgcn_s_memrealtime(); }
-
 // All vector-memory operations this wavefront has issued (loads, stores, atomics -- gfx9 counts them in one counter) have
 // completed.  Between write-through / atomic accesses this is all the ordering an agent-scope hand-off needs.
 NDZIP_DEV void wait_for_own_memory_operations() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -48,11 +48,6 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
     limit, or ASAN_FLAGS for the memory-safety run of tests/test_wavesim_asan.py), suffixed _<variant>."""
     OUT = os.path.join(HERE, f"libndzip_hip_wavesim{'_' + variant if variant else ''}.so")
     BUILD = os.path.join(HERE, "_build", variant or "default")
-    # The look-back's give-up budget is a wall-clock time (0.5 s on the GPU).  The model runs the workgroups as host fibers,
-    # orders of magnitude slower and at the mercy of whatever else the machine is doing: unless a test asks for a budget of its
-    # own (the spin-limit-0 variant) it gets 60 s -- a legitimate wait must never look like a time-out here.
-    if not any(d.startswith("NDZIP_LOOKBACK_SPIN_LIMIT") for d in defines):
-        defines = tuple(defines) + ("NDZIP_LOOKBACK_SPIN_LIMIT=6000000000ull",)
     FLAGS = list(globals()["FLAGS"]) + [f"-D{d}" for d in defines] + list(extra_flags)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in _sources()):
         return OUT

@@ -5,7 +5,6 @@
 
 #include <hip/hip_runtime.h>
 
-#include <chrono>
 #include <cstdint>
 #include <cstring>
 
@@ -56,11 +55,6 @@ NDZIP_DEV int wave_uniform(int x) { return x; }  // (the caller's claim; the val
 NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction scheduling only)
 
 NDZIP_DEV int32_t opaque_vgpr(int32_t x) { return x; }
-
-// 100 MHz ticks of a steady host clock
-NDZIP_DEV unsigned long long realtime_ticks() {
-    return static_cast<unsigned long long>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
-}
 
 NDZIP_DEV void wait_for_own_memory_operations() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
