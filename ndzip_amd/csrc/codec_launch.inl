@@ -369,8 +369,6 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     char *zero = zero_region + L::template zero_offset<Dims>() + grp0 * (C::cube_stride % 256);
     uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
 
-    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
-
     const uint32_t ntiles = (gg.nhc + K - 1) / K;
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
@@ -382,7 +380,12 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     // optimizer: it turns the single-lane atomicAdd into mbcnt + atomic + readfirstlane and waits for the result at once).
     // A whole extra tile of look-ahead was measured in round 1 and loses (0.255 vs 0.205 ms: claim order and processing order
     // drift apart and the look-back waits); this is a quarter of an iteration.
-    if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
+    // (the first ticket's round trip is the first thing on the kernel's critical path: drawn before anything else, with the
+    // zero block filled while it is in flight)
+    uint32_t first_ticket = 0;
+    if (tid == 0) first_ticket = atomicAdd(ticket_counter, 1u);
+    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
+    if (tid == 0) misc[NW + 2] = first_ticket;
     __syncthreads();
     // (tickets are the same in every lane: as scalars, so that the tile's origin -- two magic-number divisions and 64-bit
     // multiply-adds -- is computed once on the scalar unit, not per lane)
@@ -570,13 +573,15 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     char *zero = zero_region + L::zero_offset;
     uint32_t *misc = reinterpret_cast<uint32_t *>(zero_region + L::zero_bytes);  // [0..NW) wave totals, [NW] prefix, [NW+1] next ticket, [NW+2] first ticket
 
-    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
-
     const uint32_t ntiles = gg.nhc;
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
-    // tickets: see compress_kernel_db (first one in its own slot, every later one drawn behind the B3 before its consumer's B1)
-    if (tid == 0) misc[NW + 2] = atomicAdd(ticket_counter, 1u);
+    // tickets: see compress_kernel_db (first one in its own slot -- drawn first of all, the zero block is filled while it is in
+    // flight --, every later one drawn behind the B3 before its consumer's B1)
+    uint32_t first_ticket = 0;
+    if (tid == 0) first_ticket = atomicAdd(ticket_counter, 1u);
+    for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
+    if (tid == 0) misc[NW + 2] = first_ticket;
     __syncthreads();
     uint32_t tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 2]))), cls, num_classes);
 
