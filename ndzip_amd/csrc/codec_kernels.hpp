@@ -814,7 +814,9 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
 #pragma unroll
         for (int j = 0; j < 16; ++j) r[16 + j] += r[j];
         const int yp = t & 7;
-        const uint32_t keep1 = yp >= 1 ? ~0u : 0u, keep2 = yp >= 2 ? ~0u : 0u;
+        // (the masks as opaque register values: hipcc then folds the row shift into the AND -- v_and_b32_dpp -- where a select on
+        // the comparison made it v_mov_b32_dpp + v_cndmask: 48 instructions less per work-item)
+        const uint32_t keep1 = static_cast<uint32_t>(opaque_vgpr(yp >= 1 ? -1 : 0)), keep2 = static_cast<uint32_t>(opaque_vgpr(yp >= 2 ? -1 : 0));
 #pragma unroll
         for (int j = 0; j < 16; ++j) r[16 + j] += group8_shift_up<1>(r[16 + j], keep1);
 #pragma unroll

@@ -736,16 +736,28 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
         mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(src) / sizeof(W)) % wpv);
         const vec16 *src16 = reinterpret_cast<const vec16 *>(src - mis);
         const uint32_t nvec = (len + mis + wpv - 1) / wpv;
+        // 32-bit profiles, branch-free: every work-item loads and stores all of its vector slots.  Slots behind the run
+        // (j >= nvec: about a third of them on the benchmark data) load the run's LAST block again (a valid address; the lanes of
+        // a wave-instruction that do so hit one line) and park the copy behind the run in LDS, where nothing looks -- the staging
+        // region holds exactly vec_per_thread * 128 vectors.  (The conditional form is 18 exec-mask diamonds in a kernel of ~330
+        // scalar-side instructions: 327 -> 269, and 42 VALU instructions less.)  64-bit profiles keep the conditional form: their
+        // runs fill four fifths of the slots and every parked vector would pay the run layout's swizzle arithmetic.
+        static_assert(static_cast<uint32_t>(vec_per_thread) * threads_per_hc * 16u <= L::cube_bytes, "parked vectors stay inside the staging region");
+        constexpr bool branch_free = sizeof(W) == 4;
         vec16 v[vec_per_thread];
 #pragma unroll
         for (int i = 0; i < vec_per_thread; ++i) {
             const uint32_t j = static_cast<uint32_t>(i * threads_per_hc + t);
-            if (j < nvec) v[i] = global_load16_block(src16 + j);  // (read once; the end blocks may hold foreign words)
+            if constexpr (branch_free) {
+                v[i] = global_load16_block(src16 + (j < nvec ? j : nvec - 1));
+            } else {
+                if (j < nvec) v[i] = global_load16_block(src16 + j);  // (read once; the end blocks may hold foreign words)
+            }
         }
 #pragma unroll
         for (int i = 0; i < vec_per_thread; ++i) {
             const uint32_t j = static_cast<uint32_t>(i * threads_per_hc + t);
-            if (j < nvec) lds_write16(run_layout<W>::ptr(cube + 16 * j), v[i]);
+            if (branch_free || j < nvec) lds_write16(run_layout<W>::ptr(cube + 16 * j), v[i]);
         }
     }
     __syncthreads();
