@@ -846,9 +846,11 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
             vec16 all[NV];  // (every read issued before the first store: one LDS round trip instead of NV)
 #pragma unroll
             for (int i = 0; i < NV; ++i) all[i] = lds_read16(cube + L::off(static_cast<uint32_t>(i * threads_per_hc + t) * VE));
+            // global address = (wave-uniform: the hypercube's origin + i x 2 KiB, scalar arithmetic) + (one 32-bit per-lane offset)
+            char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin));
+            const uint32_t lane_bytes = lane_offset_here(static_cast<uint32_t>(t) * 16u);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const uint32_t k = static_cast<uint32_t>(i * threads_per_hc + t) * VE;
                 vec16 v = all[i];
                 if constexpr (sizeof(W) == 4) {
 #pragma unroll
@@ -861,7 +863,8 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
                         v.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
                     }
                 }
-                global_store16<Aligned>(out + origin + k, v);
+                global_store16<Aligned>(dst + lane_bytes, v);
+                dst = scalar_pointer(dst + threads_per_hc * 16);
             }
         }
     } else if constexpr (Dims == 2) {
@@ -877,24 +880,30 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
 #pragma unroll 8
         for (uint32_t y = y0; y < y0 + 32; ++y) {
             acc += lds_read<W>(cube, L::off(y * 64 + x));
-            out[origin + static_cast<uint64_t>(y) * gg.stride[0] + x] = rotr1(acc);
+            // (uniform: the hypercube's row y; per lane: the column)
+            *reinterpret_cast<W *>(reinterpret_cast<char *>(scalar_pointer(out + origin + static_cast<uint64_t>(y) * gg.stride[0]))
+                    + lane_offset_here(x * static_cast<uint32_t>(sizeof(W)))) = rotr1(acc);
         }
     } else {
         // work-item = (y, pair of x) for all 16 z
         const uint32_t y = static_cast<uint32_t>(t) >> 3, xp = static_cast<uint32_t>(t) & 7u;
         W acc0 = 0, acc1 = 0;
-        // one global pointer advanced by a plane per step and one LDS base with immediate offsets (a plane is 8 padded
-        // chunks): no per-step 64-bit multiply-adds
-        W *dst = out + origin + static_cast<uint64_t>(y) * gg.stride[1] + 2 * xp;
+        // one LDS base with immediate offsets (a plane is 8 padded chunks);
+        // global address = (wave-uniform: hypercube origin + z planes, a running scalar pointer) + (32-bit per-lane byte offset
+        // inside a plane: row y, values 2 xp .. 2 xp + 1) -- no 64-bit per-lane pointer advanced by 64-bit VALU additions
+        const uint32_t lane_bytes = (y * static_cast<uint32_t>(gg.stride[1]) + 2 * xp) * static_cast<uint32_t>(sizeof(W));
+        const uint64_t plane_step = gg.stride[0] * sizeof(W);
+        char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin));
         const char *src = cube + L::off(y * 16 + 2 * xp);
         constexpr uint32_t plane_bytes = L::off(256);
         if constexpr (sizeof(W) == 4) {
 #pragma unroll
-            for (uint32_t z = 0; z < 16; ++z, dst += gg.stride[0]) {
+            for (uint32_t z = 0; z < 16; ++z) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(src + z * plane_bytes);
                 acc0 += v.x;
                 acc1 += v.y;
-                global_store8<Aligned>(dst, rotr1(acc0), rotr1(acc1));
+                global_store8<Aligned>(dst + lane_offset_here(lane_bytes), rotr1(acc0), rotr1(acc1));
+                dst = scalar_pointer(dst + plane_step);
             }
         } else {
             // all 16 reads first: written as one loop, hipcc serialises "ds_read_b128, s_waitcnt lgkmcnt(0), add, store" 16 times
@@ -903,7 +912,7 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
 #pragma unroll
             for (uint32_t z = 0; z < 16; ++z) v[z] = lds_read16(src + z * plane_bytes);
 #pragma unroll
-            for (uint32_t z = 0; z < 16; ++z, dst += gg.stride[0]) {
+            for (uint32_t z = 0; z < 16; ++z) {
                 acc0 += static_cast<uint64_t>(v[z].w[0]) | (static_cast<uint64_t>(v[z].w[1]) << 32);
                 acc1 += static_cast<uint64_t>(v[z].w[2]) | (static_cast<uint64_t>(v[z].w[3]) << 32);
                 const uint64_t o0 = rotr1(acc0), o1 = rotr1(acc1);
@@ -912,7 +921,8 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
                 w.w[1] = static_cast<uint32_t>(o0 >> 32);
                 w.w[2] = static_cast<uint32_t>(o1);
                 w.w[3] = static_cast<uint32_t>(o1 >> 32);
-                global_store16<Aligned>(dst, w);
+                global_store16<Aligned>(dst + lane_offset_here(lane_bytes), w);
+                dst = scalar_pointer(dst + plane_step);
             }
         }
     }

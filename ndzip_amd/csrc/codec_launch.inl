@@ -749,9 +749,10 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
         for (int i = 0; i < vec_per_thread; ++i) {
             const uint32_t j = static_cast<uint32_t>(i * threads_per_hc + t);
             if constexpr (branch_free) {
-                v[i] = global_load16_block(src16 + (j < nvec ? j : nvec - 1));
+                // (wave-uniform base: the run's first block; per lane: 16 bytes x the slot, 32 bits)
+                v[i] = global_load16_block(reinterpret_cast<const char *>(scalar_pointer(src16)) + lane_offset_here(16u * (j < nvec ? j : nvec - 1)));
             } else {
-                if (j < nvec) v[i] = global_load16_block(src16 + j);  // (read once; the end blocks may hold foreign words)
+                if (j < nvec) v[i] = global_load16_block(reinterpret_cast<const char *>(scalar_pointer(src16)) + lane_offset_here(16u * j));  // (read once; the end blocks may hold foreign words)
             }
         }
 #pragma unroll
