@@ -157,8 +157,8 @@ NDZIP_HIP_API int ndzip_hip_decompressor_destroy(ndzip_hip_decompressor *d);
  * with events (kernel_ns, may be NULL), D2H copy of length and stream.  `stream` must hold
  * compressed_length_bound words; *stream_length_words receives the return value of the reference call.
  * A launch whose device-wide scan timed out (NDZIP_HIP_ERR_DEVICE_FAULT, "scan look-back timeout": the persistent grid was not
- * fully resident, e.g. on a GPU shared with another process) is repeated ONCE -- the array is still on the device -- before the
- * error is returned; kernel_ns is that of the last launch. */
+ * fully resident, e.g. on a GPU shared with another process) is repeated ONCE -- the array is still on the device; the retry runs
+ * one workgroup per CU, a grid a shared GPU is far more likely to hold in full -- before the error is returned; kernel_ns is that of the last launch. */
 NDZIP_HIP_API int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, const void *data, void *stream,
         uint32_t *stream_length_words, uint64_t *kernel_ns);
 

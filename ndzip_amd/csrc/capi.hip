@@ -213,6 +213,7 @@ struct ndzip_hip_compressor {
     uint32_t *err;
     int num_cus;
     int device;          // the device the handle was created on (and launches on)
+    int max_blocks_per_cu;  // 0 = full persistent grid; set to 1 for the relaunch after a look-back time-out (host-pointer paths)
     size_t desc_count;   // entries of `desc`
     uint32_t epoch;      // launches on `desc` so far (descriptor epoch, codec_launch.inl)
 };
@@ -275,7 +276,7 @@ int ndzip_hip_compressor_create(int dtype, int dims, uint32_t max_num_hypercubes
     if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");  // common.hh:642
     int cus = 0, device = 0;
     if (int s = ensure_device(&cus, &device)) return s;
-    auto *c = new ndzip_hip_compressor{dtype, dims, max_num_hypercubes, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, cus, device, 0, 0};
+    auto *c = new ndzip_hip_compressor{dtype, dims, max_num_hypercubes, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, cus, device, 0, 0, 0};
     const uint32_t tiles = dtype == NDZIP_HIP_F32 ? compress_num_tiles<float>(dims, max_num_hypercubes)
                                                   : compress_num_tiles<double>(dims, max_num_hypercubes);
     c->desc_count = static_cast<size_t>(tiles) + scratch_extra_descs;
@@ -323,6 +324,7 @@ static int compress_common(ndzip_hip_compressor *c, const void *d_in, int dims, 
     a.stream = c->stream;
     a.num_cus = c->num_cus;
     a.device = c->device;
+    a.max_blocks_per_cu = c->max_blocks_per_cu;
     a.aligned = is_aligned(c->dtype, gg, d_in);
     if (verbose()) fprintf(stderr, "[ndzip-hip] compress: %u hypercubes, %llu border elements\n", gg.nhc,
             static_cast<unsigned long long>(bg.count));
@@ -526,8 +528,9 @@ int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, cons
     int status = NDZIP_HIP_OK;
     // A look-back that timed out (a predecessor tile's workgroup did not publish within the poll budget: the persistent grid
     // was not fully resident, e.g. because another process held part of the GPU) spoils this launch only: the input is still on
-    // the device, so the launch is repeated ONCE before the caller sees NDZIP_HIP_ERR_DEVICE_FAULT.  (The device-pointer entry
-    // points cannot do that -- they never synchronise; their callers see the fault in ndzip_hip_compressor_check().)
+    // the device, so the launch is repeated ONCE -- with one workgroup per CU instead of four, a grid that is far more likely
+    // to be resident in full -- before the caller sees NDZIP_HIP_ERR_DEVICE_FAULT.  (The device-pointer entry points cannot do
+    // that -- they never synchronise; their callers see the fault in ndzip_hip_compressor_check().)
     for (int attempt = 0;; ++attempt) {
         if (timed) {
             if (!ev.start && (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess)) {
@@ -550,6 +553,7 @@ int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, cons
         status = check_error_word(c->err, c->stream, &bits);
         if (status == NDZIP_HIP_ERR_DEVICE_FAULT && bits == err_lookback_timeout && attempt == 0) {
             if (verbose()) fprintf(stderr, "[ndzip-hip] scan look-back timeout: relaunching once\n");
+            c->max_blocks_per_cu = 1;  // (a quarter of the grid: what a GPU shared with another process is far more likely to hold in full)
             continue;
         }
         if (status == NDZIP_HIP_ERR_DEVICE_FAULT && attempt > 0) status = fail(status, g_last_error + " -- again after one relaunch");
@@ -838,7 +842,10 @@ int offloader_wait_impl(ndzip_hip_offloader *o, int slot, void *dest, uint64_t d
         if (st == NDZIP_HIP_ERR_DEVICE_FAULT && bits == err_lookback_timeout) {
             // the array is still in the slot's device buffer: one relaunch (see ndzip_hip_offload_compress)
             if (verbose()) fprintf(stderr, "[ndzip-hip] slot %d: scan look-back timeout: relaunching once\n", slot);
-            if (int e = ndzip_hip_compressor_compress(s->comp, s->d_array, o->dims, s->extent, s->d_stream, s->d_len)) return e;
+            s->comp->max_blocks_per_cu = 1;  // (one workgroup per CU for the retry; the slot goes back to the full grid afterwards)
+            const int e = ndzip_hip_compressor_compress(s->comp, s->d_array, o->dims, s->extent, s->d_stream, s->d_len);
+            s->comp->max_blocks_per_cu = 0;
+            if (e) return e;
             HIP_TRY(hipMemcpyAsync(s->h_len, s->d_len, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
             st = check_error_word(s->comp->err, s->comp->stream, &bits);
             if (st == NDZIP_HIP_ERR_DEVICE_FAULT) st = fail(st, g_last_error + " -- again after one relaunch");

@@ -31,6 +31,8 @@ struct compress_args {
     hipStream_t stream;
     int num_cus;
     int device;            // HIP device ordinal the launch goes to (keys the per-device occupancy cache)
+    int max_blocks_per_cu; // 0 = as many workgroups per CU as are resident; > 0 caps it (the relaunch after a look-back time-out runs
+                           // one workgroup per CU: a grid a shared GPU is far more likely to hold in full)
     bool aligned;          // 16-byte aligned base and row strides
 };
 

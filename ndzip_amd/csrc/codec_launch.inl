@@ -991,6 +991,7 @@ struct occupancy_cache {
 // ticket counters on its way out (the owner of the scratch zeroes everything once).
 template<typename Kernel, typename W>
 hipError_t launch_persistent(Kernel kernel, int threads, uint32_t smem_bytes, int blocks_per_cu, uint32_t ntiles, const compress_args &a) {
+    if (a.max_blocks_per_cu > 0 && blocks_per_cu > a.max_blocks_per_cu) blocks_per_cu = a.max_blocks_per_cu;
     uint32_t grid = static_cast<uint32_t>(a.num_cus) * static_cast<uint32_t>(blocks_per_cu);
     if (grid > ntiles) grid = ntiles;
     // (a grid smaller than the class count would leave classes without a workgroup, i.e. tiles nobody draws)
