@@ -212,3 +212,44 @@ def test_shipped_kernels_use_no_flat_or_scratch_memory(tmp_path):
     assert not [o for o in ops if o.startswith(("flat_", "scratch_"))]
     assert sum(o.startswith("ds_") for o in ops) > 1000 and sum(o.startswith("global_load") for o in ops) > 300
     assert text.count(" nt") > 100 and text.count(" sc1") > 50
+
+
+def test_exec_masked_plane_compaction_has_the_shape_it_was_written_in(tmp_path):
+    """The branch-free plane compaction of the f32 compress kernels is inline assembly that changes EXEC (gfx950_lds.hpp:
+    lds_append_nonzero).  In the disassembly of the built library every v_cmpx must be followed by its store, its address
+    increment and the restore of EXEC from the SGPR pair that EXEC was saved to at the head of the sequence -- nothing the compiler
+    scheduled may sit inside a masked stretch -- and every sequence of 32 must end in the s_nop that covers the DPP / v_readlane
+    hazard after a VALU write of EXEC."""
+    import re
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    lib = shutil.copy(hip.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, capture_output=True, text=True, check=True)
+    text = ""
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" in f:
+            text += subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
+    ins = [line.split("\t")[1].split("//")[0].strip() for line in text.splitlines() if line.startswith("\t") and len(line.split("\t")) > 1 and line.split("\t")[1].strip()]
+    at = [i for i, s in enumerate(ins) if s.startswith("v_cmpx_ne_u32")]
+    # 7 instantiations of compress_kernel_db + the f32 encode stage kernels (3 dims x aligned / unaligned), 32 planes each
+    assert len(at) % 32 == 0 and len(at) >= 7 * 32, len(at)
+    for n, i in enumerate(at):
+        m = re.match(r"v_cmpx_ne_u32_e32 vcc, 0, (v\d+)$", ins[i])
+        assert m, ins[i]
+        word = m.group(1)
+        st = re.match(rf"ds_write_b32 (v\d+), {word}$", ins[i + 1])
+        assert st, ins[i:i + 4]
+        assert ins[i + 2] == f"v_add_u32_e32 {st.group(1)}, 4, {st.group(1)}", ins[i:i + 4]
+        rs = re.match(r"s_mov_b64 exec, (s\[\d+:\d+\])$", ins[i + 3])
+        assert rs, ins[i:i + 4]
+        if n % 32 == 0:  # head of a sequence: EXEC was saved to that very pair just before (hazard nops may sit in between)
+            before = [s for s in ins[max(0, i - 4):i] if s == f"s_mov_b64 {rs.group(1)}, exec"]
+            assert before, ins[max(0, i - 4):i + 4]
+            saved = rs.group(1)
+        assert rs.group(1) == saved
+        if n % 8 == 7:   # end of an asm statement
+            assert ins[i + 4] == "s_nop 1", ins[i:i + 6]
