@@ -325,8 +325,8 @@ NDZIP_DEV void copy_out(const W *__restrict__ src, W *dst_any, uint32_t n, int t
 //     streaming load), which is now hidden, and the predecessors have had a whole iteration to publish;
 //   * the next tile's input is prefetched a whole iteration ahead, so HBM stays busy during compute.
 // The encoded tile waits in REGISTERS (its 32 transposed planes per work-item), not in a second LDS buffer: the LDS
-// footprint stays at one staging region per hypercube (37 KiB per workgroup) and the register budget of 168 still
-// admits 3 workgroups = 12 wavefronts per CU (a second LDS buffer allowed only 2; measured 0.27 vs 0.32 ms).
+// footprint stays at one staging region per hypercube (37 KiB per workgroup), which with 128 VGPRs admits 4 workgroups =
+// 16 wavefronts per CU (rounds 1-2: 168 VGPRs, 3 workgroups; a second LDS buffer allowed only 2: measured 0.27 vs 0.32 ms).
 template<typename T, int Dims, bool Paired>
 struct db_cfg {
     using C = tile_cfg<T, Dims>;
