@@ -59,6 +59,10 @@ def pytest_sessionstart(session):
 
 
 def pytest_collection_modifyitems(config, items):
+    # The driver runs `-m gpu -x`: the first failure ends the run.  Tests that could never be rehearsed on the functional model
+    # (hardware_only: tools linked against the real runtime, the memory-mapped CLI path, multi-process runs) go to the END of the
+    # session, so that a surprise in one of them cannot hide the parity results of everything that was rehearsed.
+    items.sort(key=lambda item: 1 if "hardware_only" in item.keywords else 0)  # (stable: the order inside each class stays)
     if not config.getoption("--rehearse-on-model"):
         return
     skip = pytest.mark.skip(reason="hardware only: not part of the rehearsal on the functional model")

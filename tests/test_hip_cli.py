@@ -30,7 +30,7 @@ def cli(hiplib):
 
 @pytest.mark.hardware_only  # (the binaries link the real library; tests/test_cli_cpu.py runs them linked against the model)
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{np.dtype(c[0]).name}-{len(c[1])}d-x{c[2]}")
-@pytest.mark.parametrize("slots,mmap", [(1, True), (3, True), (3, False)], ids=["1slot-mmap", "3slots-mmap", "3slots-stdio"])
+@pytest.mark.parametrize("slots,mmap", [(3, False), (1, False), (1, True), (3, True)], ids=["3slots-stdio", "1slot-stdio", "1slot-mmap", "3slots-mmap"])
 def test_cli_files_are_the_reference_tools_files(cli, cuda_device, tmp_path, case, slots, mmap):
     dtype, shape, n = case
     io = ["--mmap"] if mmap else ["--no-mmap"]  # src/io/io.cc: mapped files (here opt-in) or stdio (and for pipes)
