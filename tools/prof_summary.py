@@ -77,6 +77,19 @@ def main():
             for c, v in sorted(acc[k].items()):
                 print(f"    {c:28s} n={len(v):4d} avg={sum(v) / len(v):16.1f}")
                 averages[k][c] = sum(v) / len(v)
+    # derived: how many wavefronts were resident per CU on average (the census the persistent grid's sizing rests on: 16 = four
+    # 256-thread workgroups per CU), waiting and VALU shares of the wave time.  SQ_* wave counters tick in quad-cycles
+    # (MI355X guide), GRBM_GUI_ACTIVE in cycles; both are per launch here.
+    print("# derived")
+    for k, c in sorted(averages.items()):
+        if "SQ_WAVE_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+            cus = float(os.environ.get("NDZIP_PROF_CUS", "256"))
+            print(f"{k}: average resident wavefronts per CU = {4 * c['SQ_WAVE_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * cus):.1f} (of {cus:.0f} CUs)")
+        if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c:
+            print(f"{k}: SQ_WAIT_ANY / SQ_WAVE_CYCLES = {c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']:.2f}"
+                  + (f", SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {c['SQ_ACTIVE_INST_VALU'] / c['SQ_WAVE_CYCLES']:.2f}" if "SQ_ACTIVE_INST_VALU" in c else ""))
+        if c.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in c:
+            print(f"{k}: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = {c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE']:.2f}")
     if traffic:
         import json
 
