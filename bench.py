@@ -70,7 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--noise-mask", type=lambda s: int(s, 0), default=0xFF)
     ap.add_argument("--smooth", action="store_true", help="highly compressible bookend (two low-frequency octaves)")
     ap.add_argument("--data", type=str, default="synthetic", choices=["synthetic", "random", "zeros"])
-    ap.add_argument("--sync-header-gather", action="store_true", help="N > 1: wait for the header all-gather before decompress (default: leave it in flight behind it)")
+    ap.add_argument("--sync-exchange", action="store_true", help="N > 1: finish the offset / header exchange before decompress (default: it runs behind the decompress launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true")
@@ -408,9 +408,11 @@ def main(argv=None):
     mode = "compress" if args.compress_only else "decompress" if (args.decompress_only or cfg_mode == "decompress") else "both"
     dims = len(global_extent)
     t_dtype = torch.float32 if np_dtype == np.float32 else torch.float64
-    # N > 1: the header all-gather (8 x 128 KiB at N = 8) is left in flight behind the decompress launch, which needs nothing from
-    # it (ndzip_amd/sharded.py); --sync-header-gather waits for it before decompress instead
-    codec = ShardedCodec(np_dtype, global_extent, rank, world, device, async_header_gather=world > 1 and not args.sync_header_gather)
+    # N > 1: the offset / header exchange (all-gather of one length per rank, base + global offsets, all-gather of the header
+    # segments: 8 x 128 KiB at N = 8) runs BEHIND the decompress launch, which decodes the rank's slab from its local offsets and
+    # needs nothing from the other ranks (ndzip_amd/sharded.py: overlap_exchange); --sync-exchange puts it between the two
+    # launches instead (compress -> exchange -> decompress, every collective waited for)
+    codec = ShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and not args.sync_exchange)
     shard = codec.shard
 
     # ---- synthetic input, generated directly in HBM (identical bits on every machine) ------------------------------
@@ -535,7 +537,7 @@ def main(argv=None):
                 "compression_ratio": round(ratio, 4),
                 "step": {"both": "compress then decompress", "compress": "compress only", "decompress": "decompress only"}[mode]
                         + ", inputs resident in HBM",
-                "parallelism": f"hypercube-range sharding x{world}" + (" (RCCL all-gather of offsets + header)" if world > 1 else ""),
+                "parallelism": f"hypercube-range sharding x{world}" + ((" (RCCL all-gather of offsets + header" + (")" if args.sync_exchange else ", behind the decompress launch)")) if world > 1 else ""),
             },
             "per_gpu": {},
             "roofline": roofline,

@@ -11,7 +11,9 @@ The reference has no distributed runtime; this follows SUR
     rank r's body lives at global body offset base_r, and the global stream is the concatenation
     [header][body_0]...[body_{R-1}][border_0]...[border_{R-1}] -- a host/file-level operation outside the
     timed region (`assemble_stream`), byte-identical to the single-GPU stream;
-  * decompression needs no collective: a rank decodes its slab from its header slice, its base and its body.
+  * decompression needs no collective: a rank decodes its slab from its header slice, its base and its body -- or, while
+    the exchange of the compress() before it is still in flight (`overlap_exchange`), from its local offsets, with the
+    exchange running behind the decode kernel.
 
 The exchange is written against torch.distributed only, so the same code runs over RCCL (backend "nccl",
 device tensors) on the GPU box and over gloo (CPU tensors) in the world_size-2 CPU tests.
@@ -109,7 +111,8 @@ class ShardedCodec:
     lengths, added to the local header entries) -> all-gather of the header segments.  The steps are public so that a test
     can play every rank of a plan on one GPU."""
 
-    def __init__(self, dtype, global_extent: Sequence[int], rank: int, world: int, device, group=None, async_header_gather: bool = False):
+    def __init__(self, dtype, global_extent: Sequence[int], rank: int, world: int, device, group=None, async_header_gather: bool = False,
+                 overlap_exchange: bool = False):
         import numpy as np
         import torch
 
@@ -122,6 +125,12 @@ class ShardedCodec:
         # True leaves the header all-gather in flight behind decompress (off until it has run on a multi-GPU node; the
         # default issues it synchronously on the process group's stream)
         self.async_header_gather = async_header_gather
+        # True: compress() only STARTS the exchange (the all-gather of the body lengths, asynchronously); a decompress() that
+        # follows decodes the slab from its LOCAL offsets -- it needs nothing from the other ranks -- and the rest of the exchange
+        # (base + global offsets, header all-gather) is enqueued behind it, so both collectives run under the decode kernel.
+        # Whoever reads header_global / base32, calls check() or compresses again completes the exchange first.
+        self.overlap_exchange = overlap_exchange
+        self._lengths_pending = None  # the length all-gather of the last compress(), not yet followed by globalise()
         self.device = device
         self.shards = plan_shards(self.extent, world)
         self.shard = self.shards[rank]
@@ -159,6 +168,7 @@ class ShardedCodec:
 
     def finish(self) -> None:
         """Wait (stream-wise) for the header all-gather of the last compress()."""
+        self._complete_exchange()
         if self._pending is not None:
             self._pending.wait()
             self._pending = None
@@ -188,10 +198,21 @@ class ShardedCodec:
             # single shard: local offsets are global offsets, nothing to exchange
             self._header_global = self.header_local[: sh.num_hypercubes]
             return
+        if self.overlap_exchange:
+            self._lengths_pending = dist.all_gather_into_tensor(self.lens_all, self.body_len, group=self.group, async_op=True)
+            return
         dist.all_gather_into_tensor(self.lens_all, self.body_len, group=self.group)   # world x 4 bytes
+        self._gather_headers()
+
+    def _gather_headers(self) -> None:
+        """lens_all has landed (or its wait is enqueued): base + global offsets, then the header all-gather."""
+        import torch
+        import torch.distributed as dist
+
+        sh = self.shard
         self.globalise()
         m = max(self.sizes)
-        if m > 0 and all(n == m for n in self.sizes) and self.async_header_gather:
+        if m > 0 and all(n == m for n in self.sizes) and (self.async_header_gather or self.overlap_exchange):
             if self._header_global is None or self._header_global.numel() != self.world * m:
                 self._header_global = torch.empty(self.world * m, dtype=torch.int32, device=self.device)
             self._pending = dist.all_gather_into_tensor(self._header_global, self.header_local[:m], group=self.group, async_op=True)
@@ -200,11 +221,24 @@ class ShardedCodec:
             self._header_global = gather_headers(self.header_local[: sh.num_hypercubes], self.sizes, self.world, self.group,
                                                  out=self._header_global)
 
+    def _complete_exchange(self) -> None:
+        """overlap_exchange: the part of compress() that was left for later (no-op otherwise / when already done)."""
+        if self._lengths_pending is not None:
+            self._lengths_pending.wait()
+            self._lengths_pending = None
+            self._gather_headers()
+
     def decompress(self, local_out) -> None:
         """Decode this rank's slab from (its header entries with global offsets, its base, its resident body).  The entries
         are header_local after globalise() == header_global[hc_begin:hc_end]; the base stays on the device (`base32` == the
         previous shard's last header entry).  No collective and no dependence on the header all-gather."""
         sh = self.shard
+        if self._lengths_pending is not None:
+            # the exchange of the last compress() is still at its first step: header_local holds LOCAL offsets (base 0) -- decode
+            # from those, then let the exchange continue behind the decode kernel
+            self.decompressor.decompress_split(self.header_local, None, self.body, local_out, sh.extent)
+            self._complete_exchange()
+            return
         self.decompressor.decompress_split(self.header_local, self.base32, self.body, local_out, sh.extent)
 
     def check(self) -> None:

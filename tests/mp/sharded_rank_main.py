@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--case", action="append", required=True)
     ap.add_argument("--async-header-gather", action="store_true")
+    ap.add_argument("--overlap-exchange", action="store_true", help="decode from local offsets while the exchange runs behind it")
     args = ap.parse_args()
     rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -67,7 +68,8 @@ def main():
         for i, case in enumerate(args.case):
             dtype, extent, full = case_data(case)
             wdt = np.uint32 if np.dtype(dtype).itemsize == 4 else np.uint64
-            codec = ShardedCodec(dtype, extent, rank, world, device, async_header_gather=args.async_header_gather)
+            codec = ShardedCodec(dtype, extent, rank, world, device, async_header_gather=args.async_header_gather,
+                                 overlap_exchange=args.overlap_exchange)
             sh = codec.shard
             slab = torch.from_numpy(np.ascontiguousarray(full[sh.start0: sh.start0 + sh.extent[0]])).to(device)
             out = torch.zeros_like(slab)

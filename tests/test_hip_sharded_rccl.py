@@ -84,9 +84,10 @@ def check_against_oracle(world, out_dir, cases):
 @pytest.mark.gpu
 @pytest.mark.hardware_only
 @pytest.mark.skipif(_gpus() < 2, reason="needs at least 2 GPUs (one process per GPU over RCCL)")
-@pytest.mark.parametrize("async_gather", [False, True], ids=["sync-header-gather", "async-header-gather"])
-def test_all_gpus_over_rccl_reproduce_the_single_stream(tmp_path, async_gather):
+@pytest.mark.parametrize("mode", [[], ["--async-header-gather"], ["--overlap-exchange"]],
+                         ids=["sync-header-gather", "async-header-gather", "overlap-exchange"])
+def test_all_gpus_over_rccl_reproduce_the_single_stream(tmp_path, mode):
     world = _gpus()
     cases = cases_for(world)
-    launch_ranks(world, tmp_path, cases, "nccl", extra=["--async-header-gather"] if async_gather else [])
+    launch_ranks(world, tmp_path, cases, "nccl", extra=mode)
     check_against_oracle(world, tmp_path, cases)

@@ -150,8 +150,9 @@ def test_sharded_codec_on_the_model_over_gloo(tmp_path, extent, dtype, world, as
     assert len(got) == len(want) and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("world,async_gather", [(2, False), (3, True)])
-def test_rccl_parity_harness_rehearsed_over_gloo_on_the_model(tmp_path, world, async_gather):
+@pytest.mark.parametrize("world,mode", [(2, []), (3, ["--async-header-gather"]), (2, ["--overlap-exchange"]), (3, ["--overlap-exchange"])],
+                         ids=["2-sync", "3-async-header", "2-overlap", "3-overlap"])
+def test_rccl_parity_harness_rehearsed_over_gloo_on_the_model(tmp_path, world, mode):
     """tests/test_hip_sharded_rccl.py's harness -- torch.distributed.run, tests/mp/sharded_rank_main.py, assembly, oracle
     comparison -- with backend gloo and the kernels on the functional model: what runs on the first multi-GPU node is this,
     with `--backend nccl` and one GPU per rank."""
@@ -160,7 +161,7 @@ def test_rccl_parity_harness_rehearsed_over_gloo_on_the_model(tmp_path, world, a
 
     simbuild.build()  # once, before the ranks race for it
     cases = cases_for(world)
-    launch_ranks(world, tmp_path, cases, "gloo", extra=["--model"] + (["--async-header-gather"] if async_gather else []), timeout=500)
+    launch_ranks(world, tmp_path, cases, "gloo", extra=["--model"] + mode, timeout=500)
     check_against_oracle(world, tmp_path, cases)
 
 
