@@ -1,0 +1,53 @@
+"""The profile post-processing (tools/prof_summary.py) on a synthetic rocprofv3 output tree: the one GPU call a round may get runs
+tools/pmc.sh, which deletes the raw counter files after summarising them -- the summariser must not be what fails."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPRESS = ("void ndzip_hip::(anonymous namespace)::compress_kernel_db<float, 3, true, true>(unsigned int const*, ndzip_hip::grid_geom, "
+            "unsigned int*, unsigned int*, unsigned long long*, unsigned int*, unsigned int, unsigned int*, unsigned int, unsigned int*, unsigned int)")
+DECOMPRESS = ("void ndzip_hip::(anonymous namespace)::decompress_kernel<float, 3, true>(unsigned int const*, unsigned int const*, "
+              "unsigned int const*, unsigned int*, ndzip_hip::grid_geom, unsigned int*, unsigned int, unsigned int)")
+
+
+def _counters(path, values):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id", "Kernel_Name",
+                    "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name",
+                    "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+        for i in range(3):
+            for kernel in (COMPRESS, DECOMPRESS):
+                for name, value in values.items():
+                    w.writerow([i, i, 1, 1, 1, 1, 262144, 1, kernel, 256, 37888, 0, 128, 0, 112, name, value, 0, 1])
+
+
+def test_prof_summary_on_a_synthetic_rocprofv3_tree(tmp_path):
+    os.makedirs(tmp_path / "stats")
+    with open(tmp_path / "stats" / "stats_kernel_trace.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kind", "Agent_Id", "Queue_Id", "Kernel_Id", "Kernel_Name", "Correlation_Id", "Start_Timestamp", "End_Timestamp"])
+        for i in range(6):
+            w.writerow(["KERNEL_DISPATCH", 1, 1, 1, COMPRESS, i, 1000 + i * 400000, 1000 + i * 400000 + 190000])
+            w.writerow(["KERNEL_DISPATCH", 1, 1, 2, DECOMPRESS, i, 200000 + i * 400000, 200000 + i * 400000 + 165000])
+    _counters(tmp_path / "pmc1" / "pmc1_counter_collection.csv", {"SQ_WAVES": 4096, "SQ_WAVE_CYCLES": 4.0e8, "SQ_WAIT_ANY": 1.6e8, "SQ_ACTIVE_INST_VALU": 1.2e8})
+    _counters(tmp_path / "pmc2" / "pmc2_counter_collection.csv", {"SQ_LDS_BANK_CONFLICT": 2.0e6, "SQ_LDS_IDX_ACTIVE": 8.0e6})
+    _counters(tmp_path / "pmc4" / "pmc4_counter_collection.csv", {"FETCH_SIZE": 265000.0, "GRBM_GUI_ACTIVE": 430000})
+    _counters(tmp_path / "pmc5" / "pmc5_counter_collection.csv", {"WRITE_SIZE": 362000.0})
+    traffic = tmp_path / "traffic.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), str(tmp_path), "--traffic", "float32-512x512x512", str(traffic),
+                        "test"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "compress_kernel_db<float, 3, true, true>" in r.stdout and "190.00" in r.stdout and "165.00" in r.stdout   # average microseconds
+    assert "average resident wavefronts per CU = 14.5" in r.stdout and "SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.40" in r.stdout
+    assert "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25" in r.stdout
+    entry = json.loads(traffic.read_text())["float32-512x512x512"]
+    from ndzip_amd.build import kernels_fingerprint
+
+    assert entry["kernels"] == kernels_fingerprint()
+    # FETCH_SIZE doubled (gfx950: wide coalesced reads are tallied at half their bytes), KiB units
+    assert entry["compress_hbm_bytes_per_launch"] == int(265000.0 * 1024 * 2 + 362000.0 * 1024)
