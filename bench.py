@@ -70,6 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--noise-mask", type=lambda s: int(s, 0), default=0xFF)
     ap.add_argument("--smooth", action="store_true", help="highly compressible bookend (two low-frequency octaves)")
     ap.add_argument("--data", type=str, default="synthetic", choices=["synthetic", "random", "zeros"])
+    ap.add_argument("--workgroups-per-cu", type=int, default=0, help="cap the persistent compress grid (0 = default: 4 per CU); 3 = the round-2 grid, for an A/B of the occupancy")
     ap.add_argument("--sync-exchange", action="store_true", help="N > 1: finish the offset / header exchange before decompress (default: it runs behind the decompress launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg")
@@ -413,6 +414,8 @@ def main(argv=None):
     # needs nothing from the other ranks (ndzip_amd/sharded.py: overlap_exchange); --sync-exchange puts it between the two
     # launches instead (compress -> exchange -> decompress, every collective waited for)
     codec = ShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and not args.sync_exchange)
+    if args.workgroups_per_cu:
+        codec.compressor.set_max_workgroups_per_cu(args.workgroups_per_cu)
     shard = codec.shard
 
     # ---- synthetic input, generated directly in HBM (identical bits on every machine) ------------------------------

@@ -389,6 +389,13 @@ int ndzip_hip_compressor_check(ndzip_hip_compressor *c) {
     return check_error_word(c->err, c->stream);
 }
 
+int ndzip_hip_compressor_set_max_workgroups_per_cu(ndzip_hip_compressor *c, int max_workgroups_per_cu) {
+    if (!c) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle");
+    if (max_workgroups_per_cu < 0 || max_workgroups_per_cu > 64) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "workgroups per CU: 0 (default) .. 64");
+    c->max_blocks_per_cu = max_workgroups_per_cu;
+    return NDZIP_HIP_OK;
+}
+
 int ndzip_hip_compressor_destroy(ndzip_hip_compressor *c) {
     if (!c) return NDZIP_HIP_OK;
     (void) hipStreamSynchronize(c->stream);
@@ -554,7 +561,7 @@ int ndzip_hip_offload_compress(int dtype, int dims, const uint32_t *extent, cons
         if (status == NDZIP_HIP_ERR_DEVICE_FAULT && bits == err_lookback_timeout && attempt == 0) {
             if (verbose()) fprintf(stderr, "[ndzip-hip] scan look-back timeout: relaunching once\n");
             c->max_blocks_per_cu = 1;  // (a quarter of the grid: what a GPU shared with another process is far more likely to hold in full)
-            continue;
+            continue;                  // (the handle is private to this call and destroyed below)
         }
         if (status == NDZIP_HIP_ERR_DEVICE_FAULT && attempt > 0) status = fail(status, g_last_error + " -- again after one relaunch");
         break;
@@ -842,9 +849,10 @@ int offloader_wait_impl(ndzip_hip_offloader *o, int slot, void *dest, uint64_t d
         if (st == NDZIP_HIP_ERR_DEVICE_FAULT && bits == err_lookback_timeout) {
             // the array is still in the slot's device buffer: one relaunch (see ndzip_hip_offload_compress)
             if (verbose()) fprintf(stderr, "[ndzip-hip] slot %d: scan look-back timeout: relaunching once\n", slot);
-            s->comp->max_blocks_per_cu = 1;  // (one workgroup per CU for the retry; the slot goes back to the full grid afterwards)
+            const int configured = s->comp->max_blocks_per_cu;
+            s->comp->max_blocks_per_cu = 1;  // (one workgroup per CU for the retry; the slot goes back to its grid afterwards)
             const int e = ndzip_hip_compressor_compress(s->comp, s->d_array, o->dims, s->extent, s->d_stream, s->d_len);
-            s->comp->max_blocks_per_cu = 0;
+            s->comp->max_blocks_per_cu = configured;
             if (e) return e;
             HIP_TRY(hipMemcpyAsync(s->h_len, s->d_len, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
             st = check_error_word(s->comp->err, s->comp->stream, &bits);

@@ -54,6 +54,7 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_compressor_offset_header_device",
     "ndzip_hip_compressor_offset_header_gathered",
     "ndzip_hip_compressor_check",
+    "ndzip_hip_compressor_set_max_workgroups_per_cu",
     "ndzip_hip_compressor_destroy",
     "ndzip_hip_decompressor_create",
     "ndzip_hip_decompressor_decompress",
@@ -143,6 +144,7 @@ def _bind(L, strict: bool = True):
     L.ndzip_hip_compressor_offset_header_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ndzip_hip_compressor_offset_header_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ndzip_hip_compressor_check.argtypes = [C.c_void_p]
+    L.ndzip_hip_compressor_set_max_workgroups_per_cu.argtypes = [C.c_void_p, C.c_int]
     L.ndzip_hip_compressor_destroy.argtypes = [C.c_void_p]
     L.ndzip_hip_decompressor_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.ndzip_hip_decompressor_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _U32P]
@@ -286,6 +288,10 @@ class HipCompressor:
 
     def check(self) -> None:
         _check(lib().ndzip_hip_compressor_check(self._h))
+
+    def set_max_workgroups_per_cu(self, n: int) -> None:
+        """Cap the persistent compress grid at `n` workgroups per compute unit (0 = default: all that are resident)."""
+        _check(lib().ndzip_hip_compressor_set_max_workgroups_per_cu(self._h, int(n)))
 
     def close(self) -> None:
         if getattr(self, "_h", None):

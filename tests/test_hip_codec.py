@@ -270,3 +270,29 @@ def oracle_border_elements(shape):
     for e in shape:
         inner *= e // side * side
     return int(np.prod(shape)) - inner
+
+
+def test_workgroups_per_cu_cap_changes_the_grid_not_the_stream(hiplib, cuda_device):
+    """ndzip_hip_compressor_set_max_workgroups_per_cu: 1, 2 and 3 workgroups per CU (the persistent grid of rounds 1-2 was 3) and the
+    default (4) produce the same stream on one handle; the cap is a tuning / diagnosis knob without a reference counterpart."""
+    import torch
+
+    import ndzip_amd
+
+    shape = (48, 64, 96)
+    data = random_unit_floats(shape, np.float32, 5)
+    want = oracle.compress(data)
+    d_in = torch.from_numpy(data).to(cuda_device)
+    d_out = torch.zeros(ndzip_amd.compressed_length_bound(np.float32, shape), dtype=torch.int32, device=cuda_device)
+    d_len = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    comp = ndzip_amd.make_hip_compressor(np.float32, ndzip_amd.CompressorRequirements(shape), torch.cuda.current_stream().cuda_stream)
+    for cap in (3, 1, 0, 2):
+        comp.set_max_workgroups_per_cu(cap)
+        d_out.zero_()
+        comp.compress(d_in, shape, d_out, d_len)
+        comp.check()
+        n = int(d_len.cpu()[0])
+        assert np.array_equal(d_out[:n].cpu().numpy().view(np.uint32), want), cap
+    with pytest.raises(ndzip_amd.NdzipHipError):
+        comp.set_max_workgroups_per_cu(-1)
+    comp.close()

@@ -24,6 +24,8 @@ TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summa
 V="main"; for v in wg3 r02 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
 (timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt
 (timeout 600 bash tools/ab.sh "$V" --config 1 2>&1) > ${O}_ab_variants_cfg1.txt
+# the same library at 4 / 3 / 2 workgroups per CU (ndzip_hip_compressor_set_max_workgroups_per_cu): what the occupancy alone buys
+for w in 0 3 2; do echo -n "workgroups per CU $w: "; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compress-only --workgroups-per-cu $w 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('compress_ms', d['roofline']['launch_ms'], 'frac', d['roofline']['frac'])"; done > ${O}_workgroups_per_cu.txt 2>&1
 #   linear64 = 64-bit encoded runs linear in LDS (the round-1 layout) instead of XOR-swizzled (f64 only)
 V64="main"; for v in r02 linear64 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V64="$V64 $v"; done
 (AB_MODE=both timeout 600 bash tools/ab.sh "$V64" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
@@ -32,4 +34,4 @@ V64="main"; for v in r02 linear64 plainloads r01; do [ -f ndzip_amd/_variants/$v
 if [ -f ndzip_amd/_variants/timing.so ]; then
   (NDZIP_HIP_EXP=16 timeout 300 python bench.py --lib $PWD/ndzip_amd/_variants/timing.so --steps 3 --warmup 1 --no-cpu-baseline --compress-only 2>&1 | tail -40) > ${O}_phase_timing.txt
 fi
-tail -8 ${O}_gputest.txt; cat ${O}_bench_n1.json; cat ${O}_configs.txt; cat ${O}_ab_variants.txt; cat ${O}_phase_timing.txt 2>/dev/null | tail -20
+tail -8 ${O}_gputest.txt; cat ${O}_bench_n1.json; cat ${O}_configs.txt; cat ${O}_ab_variants.txt; cat ${O}_workgroups_per_cu.txt; cat ${O}_phase_timing.txt 2>/dev/null | tail -20
