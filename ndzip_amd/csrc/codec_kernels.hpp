@@ -734,26 +734,41 @@ NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *
         // the run, or the 8 bytes behind it that the staging region holds) and kept iff the bit is set -- three VALU
         // instructions per plane half instead of the mask / popcount / address / select of an indexed gather
         uint32_t hi[32], lo[32];
-        uint32_t p = lds_address(cube) + 8 * (base + cnt) + 4 * half;  // linear LDS address; the word sits at R::at(p)
-        int32_t kept_hi[32], kept_lo[32];  // 0 / -1 per plane (the kernel's occupancy is bound by LDS, not by these registers)
+        const uint32_t first = lds_address(cube) + 8 * base;  // linear LDS address of the chunk's first plane word
+        // All 64 planes present at a 16-byte aligned position (incompressible data): the chunk is 32 whole 16-byte slots, which
+        // the swizzle moves as units -- 32 ds_read_b128 (planes 2k and 2k + 1, both halves; the lane keeps its half) instead of
+        // 64 word reads at a lane stride of 512 bytes, which the swizzle spreads over only two slot positions: tools/lds_profile.py
+        // prices that gather at 8x its conflict-free cycles (random bits 2D f64: 1 792 of 3 103 LDS-pipe cycles per hypercube).
+        if ((head_lo & head_hi) == 0xffffffffu && (first & 15u) == 0) {
 #pragma unroll
-        for (int i = 31; i >= 0; --i) {
-            kept_lo[i] = opaque_vgpr(static_cast<int32_t>(head_lo << i) >> 31);
-            p = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(p + 8 * kept_lo[i])));  // (one v_lshl_add_u32; not a running count)
-            lo[i] = *reinterpret_cast<const uint32_t *>(lds_pointer(R::at(p)));
-        }
+            for (int k = 0; k < 32; ++k) {
+                const vec16 v = lds_read16(lds_pointer(R::at(first + 16u * static_cast<uint32_t>(k))));
+                uint32_t(&dst)[32] = k < 16 ? hi : lo;
+                dst[2 * (k & 15)] = upper ? v.w[1] : v.w[0];
+                dst[2 * (k & 15) + 1] = upper ? v.w[3] : v.w[2];
+            }
+        } else {
+            uint32_t p = first + 8 * cnt + 4 * half;  // linear LDS address; the word sits at R::at(p)
+            int32_t kept_hi[32], kept_lo[32];  // 0 / -1 per plane (the kernel's occupancy is bound by LDS, not by these registers)
 #pragma unroll
-        for (int i = 31; i >= 0; --i) {
-            kept_hi[i] = opaque_vgpr(static_cast<int32_t>(head_hi << i) >> 31);
-            p = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(p + 8 * kept_hi[i])));
-            hi[i] = *reinterpret_cast<const uint32_t *>(lds_pointer(R::at(p)));
-        }
-        lds_reads_issued_before_use(lo);
-        lds_reads_issued_before_use(hi);
+            for (int i = 31; i >= 0; --i) {
+                kept_lo[i] = opaque_vgpr(static_cast<int32_t>(head_lo << i) >> 31);
+                p = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(p + 8 * kept_lo[i])));  // (one v_lshl_add_u32; not a running count)
+                lo[i] = *reinterpret_cast<const uint32_t *>(lds_pointer(R::at(p)));
+            }
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            lo[i] &= static_cast<uint32_t>(kept_lo[i]);
-            hi[i] &= static_cast<uint32_t>(kept_hi[i]);
+            for (int i = 31; i >= 0; --i) {
+                kept_hi[i] = opaque_vgpr(static_cast<int32_t>(head_hi << i) >> 31);
+                p = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(p + 8 * kept_hi[i])));
+                hi[i] = *reinterpret_cast<const uint32_t *>(lds_pointer(R::at(p)));
+            }
+            lds_reads_issued_before_use(lo);
+            lds_reads_issued_before_use(hi);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                lo[i] &= static_cast<uint32_t>(kept_lo[i]);
+                hi[i] &= static_cast<uint32_t>(kept_hi[i]);
+            }
         }
         if constexpr (ComplementInPlaneDomain) {
             // hi[0] is this lane's half of the sign plane; it covers the same 32 values as all its other plane halves

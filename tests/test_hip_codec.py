@@ -89,6 +89,33 @@ def test_many_hypercubes_unaligned_and_aligned(hiplib, cuda_device, profile, kin
 
 
 @pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
+def test_dense_and_sparse_chunks_mixed(hiplib, cuda_device, profile):
+    """Chunks that keep ALL their planes take a 16-byte-access path in the encoder (f32) and the decoder (f32, f64) when
+    they start on a 16-byte boundary of the run; whether they do depends on how many planes the chunks in front of them
+    kept.  Random bits with constant spans, spans with the low bits cleared and single zeros strewn in: wavefronts in which
+    dense-aligned, dense-unaligned and ordinary chunks sit side by side, in every order."""
+    dtype, dims = profile
+    side = SIDE[dims]
+    shape = {1: (side * 6,), 2: (side * 3, side * 2), 3: (side * 2, side, side * 3)}[dims]
+    w = word_dtype(dtype)
+    bits = 8 * np.dtype(dtype).itemsize
+    rng = np.random.default_rng(4711 + dims)
+    words = random_bits(shape, dtype, 90 + dims).view(w).reshape(-1).copy()
+    n = words.size
+    for _ in range(n // 400):  # constant spans: all-zero residuals, chunks that keep few planes
+        a = int(rng.integers(0, n - 200))
+        words[a:a + int(rng.integers(1, 200))] = words[a]
+    for _ in range(n // 400):  # spans without their low k bits: chunks that keep bits - k planes or so
+        a = int(rng.integers(0, n - 200))
+        k = int(rng.integers(1, bits - 1))
+        words[a:a + int(rng.integers(1, 200))] &= w(np.iinfo(w).max >> k << k)
+    data = words.view(dtype).reshape(shape)
+    stream = _check_stream(data)
+    assert same_bits(device_decompress(stream, dtype, shape), data)
+    assert same_bits(device_decompress(oracle.compress(data), dtype, shape), data)
+
+
+@pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
 @pytest.mark.parametrize("skew", [1, 3])
 def test_element_aligned_device_pointers(hiplib, cuda_device, profile, skew):
     """Array, stream and output pointers that are only element-aligned (sub-views `skew` elements into an allocation):
