@@ -37,12 +37,19 @@ NDZIP_DEV uint32_t rotr1(uint32_t v) { return __builtin_amdgcn_alignbit(v, v, 1)
 NDZIP_DEV uint64_t rotl1(uint64_t v) { return (v << 1) | (v >> 63); }
 NDZIP_DEV uint64_t rotr1(uint64_t v) { return (v >> 1) | (v << 63); }
 
-// v >> (B-1) ? v ^ (~0 >> 1) : v   ==   v ^ (uint(sint(v) >> (B-1)) >> 1)
+// v >> (B-1) ? v ^ (~0 >> 1) : v   ==   v ^ (sign_mask & (~0 >> 1)),  sign_mask = sint(v) >> (B-1)
+// The mask goes through opaque_vgpr so that the optimiser cannot canonicalise `ashr ; and` into `ashr ; lshr ; xor` (three
+// instructions per value; five for 64 bits, two of them on a 64-bit shift): as written it selects v_ashrrev_i32 +
+// v_bitop3_b32 (x ^ (m & c)) -- and for 64 bits one v_ashrrev_i32 of the high half, v_xor of the low half, v_bitop3 of the
+// high half.  32 (f32) / 16 (f64) values per work-item and hypercube.
 NDZIP_DEV uint32_t complement_negative(uint32_t v) {
-    return v ^ (static_cast<uint32_t>(static_cast<int32_t>(v) >> 31) >> 1);
+    const uint32_t m = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(v) >> 31));
+    return v ^ (m & 0x7fffffffu);
 }
 NDZIP_DEV uint64_t complement_negative(uint64_t v) {
-    return v ^ (static_cast<uint64_t>(static_cast<int64_t>(v) >> 63) >> 1);
+    const uint32_t hi = static_cast<uint32_t>(v >> 32), lo = static_cast<uint32_t>(v);
+    const uint32_t m = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(hi) >> 31));
+    return (static_cast<uint64_t>(hi ^ (m & 0x7fffffffu)) << 32) | (lo ^ m);
 }
 
 NDZIP_DEV int popcount_w(uint32_t v) { return __builtin_popcount(v); }
