@@ -708,6 +708,10 @@ NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r[4 * i + j] = v.w[j];
             }
+            if constexpr (ComplementInPlaneDomain) {
+#pragma unroll
+                for (int i = 1; i < 32; ++i) r[i] ^= r[0];
+            }
         } else {
             // walk the present planes: the word at the running position is read speculatively (always inside the run or
             // the staging region) and kept iff the plane's head bit is set
@@ -718,12 +722,14 @@ NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *
                 pos += (head >> (31 - i)) & 1u;
             }
             lds_reads_issued_before_use(r);
+            // keep-mask and plane-domain complement in ONE three-input bit operation per plane, (word & kept) ^ sign plane
+            // (v_bitop3_b32; done behind the join of the two paths it was an AND here and an XOR there)
+            r[0] &= static_cast<uint32_t>(static_cast<int32_t>(head) >> 31);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) r[i] &= static_cast<uint32_t>(static_cast<int32_t>(head << i) >> 31);
-        }
-        if constexpr (ComplementInPlaneDomain) {
-#pragma unroll
-            for (int i = 1; i < 32; ++i) r[i] ^= r[0];
+            for (int i = 1; i < 32; ++i) {
+                const uint32_t kept = static_cast<uint32_t>(static_cast<int32_t>(head << i) >> 31);
+                r[i] = ComplementInPlaneDomain ? (r[i] & kept) ^ r[0] : r[i] & kept;
+            }
         }
         transpose32(r);
     } else {
@@ -754,6 +760,13 @@ NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *
                 dst[2 * (k & 15)] = upper ? v.w[1] : v.w[0];
                 dst[2 * (k & 15) + 1] = upper ? v.w[3] : v.w[2];
             }
+            if constexpr (ComplementInPlaneDomain) {
+                // hi[0] is this lane's half of the sign plane; it covers the same 32 values as all its other plane halves
+#pragma unroll
+                for (int i = 1; i < 32; ++i) hi[i] ^= hi[0];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) lo[i] ^= hi[0];
+            }
         } else {
             uint32_t p = first + 8 * cnt + 4 * half;  // linear LDS address; the word sits at R::at(p)
             int32_t kept_hi[32], kept_lo[32];  // 0 / -1 per plane (the kernel's occupancy is bound by LDS, not by these registers)
@@ -771,18 +784,16 @@ NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *
             }
             lds_reads_issued_before_use(lo);
             lds_reads_issued_before_use(hi);
+            // keep-mask and plane-domain complement fused: (word & kept) ^ sign plane = one v_bitop3_b32 per plane half
+            hi[0] &= static_cast<uint32_t>(kept_hi[0]);
+#pragma unroll
+            for (int i = 1; i < 32; ++i) {
+                hi[i] = ComplementInPlaneDomain ? (hi[i] & static_cast<uint32_t>(kept_hi[i])) ^ hi[0] : hi[i] & static_cast<uint32_t>(kept_hi[i]);
+            }
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                lo[i] &= static_cast<uint32_t>(kept_lo[i]);
-                hi[i] &= static_cast<uint32_t>(kept_hi[i]);
+                lo[i] = ComplementInPlaneDomain ? (lo[i] & static_cast<uint32_t>(kept_lo[i])) ^ hi[0] : lo[i] & static_cast<uint32_t>(kept_lo[i]);
             }
-        }
-        if constexpr (ComplementInPlaneDomain) {
-            // hi[0] is this lane's half of the sign plane; it covers the same 32 values as all its other plane halves
-#pragma unroll
-            for (int i = 1; i < 32; ++i) hi[i] ^= hi[0];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) lo[i] ^= hi[0];
         }
         transpose32(hi);
         transpose32(lo);
