@@ -713,22 +713,27 @@ NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *
                 for (int i = 1; i < 32; ++i) r[i] ^= r[0];
             }
         } else {
-            // walk the present planes: the word at the running position is read speculatively (always inside the run or
-            // the staging region) and kept iff the plane's head bit is set
-            uint32_t pos = base;
+            // walk the present planes from the LAST one back to the first (as the 64-bit profiles do below): the byte address
+            // steps down one word per set head bit -- v_bfe_i32 (0 / -1 per plane) and v_lshl_add_u32 p, kept, 2, p -- and the
+            // word under it is read speculatively (inside the run, or the one word behind it, which the staging region holds)
+            // and kept iff the bit is set: three VALU instructions per plane with the fused mask + complement below, where the
+            // forward walk (shift, and 4, add; mask again for the select) took five.  The 32 masks stay in registers: the
+            // decoder's occupancy is bound by its LDS (4 wavefronts per SIMD), not by them.
+            uint32_t p = lds_address(in32 + base + cnt);
+            int32_t kept[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                r[i] = in32[pos];
-                pos += (head >> (31 - i)) & 1u;
+            for (int i = 31; i >= 0; --i) {
+                kept[i] = opaque_vgpr(static_cast<int32_t>(head << i) >> 31);
+                p = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(p + 4 * kept[i])));  // (one v_lshl_add_u32; not a running count)
+                r[i] = *reinterpret_cast<const uint32_t *>(lds_pointer(p));
             }
             lds_reads_issued_before_use(r);
             // keep-mask and plane-domain complement in ONE three-input bit operation per plane, (word & kept) ^ sign plane
             // (v_bitop3_b32; done behind the join of the two paths it was an AND here and an XOR there)
-            r[0] &= static_cast<uint32_t>(static_cast<int32_t>(head) >> 31);
+            r[0] &= static_cast<uint32_t>(kept[0]);
 #pragma unroll
             for (int i = 1; i < 32; ++i) {
-                const uint32_t kept = static_cast<uint32_t>(static_cast<int32_t>(head << i) >> 31);
-                r[i] = ComplementInPlaneDomain ? (r[i] & kept) ^ r[0] : r[i] & kept;
+                r[i] = ComplementInPlaneDomain ? (r[i] & static_cast<uint32_t>(kept[i])) ^ r[0] : r[i] & static_cast<uint32_t>(kept[i]);
             }
         }
         transpose32(r);
