@@ -18,16 +18,17 @@ timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
 TRAFFIC_KEY=float32-512x512x512 timeout 900 bash tools/pmc.sh ${O}_rocprofv3_summary.txt
 TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_2d.txt --config 3
 # A/B of whatever variants were built on the CPU beforehand (tools/build_variant.sh, tools/build_history_variant.sh):
+#   r03s1 = the library at the start of the second session of round 3 (before the bitop3 complement / decoder gather changes)
 #   r02 = the round-2 library (3 workgroups per CU, branchy plane compaction, per-lane pointers), r01 = the round-1 pipeline
 #   wg3 = HEAD held to 3 wavefronts per SIMD (f32 kernels): isolates what the 4th workgroup per CU buys
 #   plainloads = HEAD without the nt input loads
-V="main"; for v in wg3 r02 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
+V="main"; for v in wg3 r03s1 r02 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
 (timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt
 (timeout 600 bash tools/ab.sh "$V" --config 1 2>&1) > ${O}_ab_variants_cfg1.txt
 # the same library at 4 / 3 / 2 workgroups per CU (ndzip_hip_compressor_set_max_workgroups_per_cu): what the occupancy alone buys
 for w in 0 3 2; do echo -n "workgroups per CU $w: "; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compress-only --workgroups-per-cu $w 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('compress_ms', d['roofline']['launch_ms'], 'frac', d['roofline']['frac'])"; done > ${O}_workgroups_per_cu.txt 2>&1
 #   linear64 = 64-bit encoded runs linear in LDS (the round-1 layout) instead of XOR-swizzled (f64 only)
-V64="main"; for v in r02 linear64 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V64="$V64 $v"; done
+V64="main"; for v in r03s1 r02 linear64 plainloads r01; do [ -f ndzip_amd/_variants/$v.so ] && V64="$V64 $v"; done
 (AB_MODE=both timeout 600 bash tools/ab.sh "$V64" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
 (AB_MODE=both timeout 600 bash tools/ab.sh "$V64" --shape 512,512,512 --dtype float64 2>&1) > ${O}_ab_variants_f64_3d.txt
 # per-phase cycle totals of the f32 compress iteration (lab build with phase timers; NDZIP_HIP_EXP=16)
