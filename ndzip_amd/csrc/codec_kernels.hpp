@@ -34,8 +34,15 @@ namespace ndzip_hip {
 
 NDZIP_DEV uint32_t rotl1(uint32_t v) { return __builtin_amdgcn_alignbit(v, v, 31); }
 NDZIP_DEV uint32_t rotr1(uint32_t v) { return __builtin_amdgcn_alignbit(v, v, 1); }
-NDZIP_DEV uint64_t rotl1(uint64_t v) { return (v << 1) | (v >> 63); }
-NDZIP_DEV uint64_t rotr1(uint64_t v) { return (v >> 1) | (v << 63); }
+// (64 bits: two v_alignbit_b32 over the register pair instead of a 64-bit shift, a 32-bit shift and an OR)
+NDZIP_DEV uint64_t rotl1(uint64_t v) {
+    const uint32_t hi = static_cast<uint32_t>(v >> 32), lo = static_cast<uint32_t>(v);
+    return (static_cast<uint64_t>(__builtin_amdgcn_alignbit(hi, lo, 31)) << 32) | __builtin_amdgcn_alignbit(lo, hi, 31);
+}
+NDZIP_DEV uint64_t rotr1(uint64_t v) {
+    const uint32_t hi = static_cast<uint32_t>(v >> 32), lo = static_cast<uint32_t>(v);
+    return (static_cast<uint64_t>(__builtin_amdgcn_alignbit(lo, hi, 1)) << 32) | __builtin_amdgcn_alignbit(hi, lo, 1);
+}
 
 // v >> (B-1) ? v ^ (~0 >> 1) : v   ==   v ^ (sign_mask & (~0 >> 1)),  sign_mask = sint(v) >> (B-1)
 // The mask goes through opaque_vgpr so that the optimiser cannot canonicalise `ashr ; and` into `ashr ; lshr ; xor` (three
