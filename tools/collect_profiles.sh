@@ -5,7 +5,7 @@
 set -e
 src=${1:?tag}; dst=${2:-$1}
 cd "$(dirname "$0")/.."
-for f in gputest bench_n1.json configs workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d ab_variants ab_variants_cfg1 ab_variants_f64_2d ab_variants_f64_3d phase_timing two_process_stress rocminfo; do
+for f in smoke gputest bench_n1.json configs workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d ab_variants ab_variants_cfg1 ab_variants_f64_2d ab_variants_f64_3d phase_timing two_process_stress rocminfo; do
   for ext in "" .txt; do
     [ -f "gpurun_out/${src}_$f$ext" ] && cp "gpurun_out/${src}_$f$ext" "profiles/${dst}_$f$ext"
   done
