@@ -51,7 +51,9 @@ def test_the_sanitised_model_does_trap():
             "    comp.compress(x.ctypes.data, x.shape, out.ctypes.data, length.ctypes.data)\n"
             "print('no trap')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=asan_env(), capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and "heap-buffer-overflow" in r.stderr, r.stdout[-500:] + r.stderr[-3000:]
+    # (the first out-of-range store of a copy-out that is far too long can land beyond the red zone, in a block some other
+    # thread has just freed: AddressSanitizer then names the same wild store a use-after-free -- seen once under a loaded machine)
+    assert r.returncode != 0 and any(k in r.stderr for k in ("heap-buffer-overflow", "heap-use-after-free")), r.stdout[-500:] + r.stderr[-3000:]
     # (the faulting frame by name or by source file: under a loaded machine the symbolizer has been seen to give up on names)
     assert any(k in r.stderr for k in ("copy_out", "copy_vectors", "codec_launch.inl", "libndzip_hip_wavesim_asan")), r.stderr[-3000:]
     assert "no trap" not in r.stdout

@@ -43,14 +43,18 @@ NDZIP_DEV vec16 lds_read16(const char *p) {
 NDZIP_DEV uint32_t lds_address(const void *p) { return static_cast<uint32_t>(static_cast<const char *>(p) - smem); }
 NDZIP_DEV char *lds_pointer(uint32_t address) { return smem + address; }
 
+// v_readfirstlane on hardware: the claim that every active lane holds the same value is CHECKED here (wavesim.cc: uniform_claim
+// aborts with the call site when a lane of the wavefront passes another value than the first one did)
 template<typename P>
-NDZIP_DEV P *scalar_pointer(P *p) { return p; }  // (register allocation only)
+NDZIP_DEV P *scalar_pointer(P *p) {
+    return reinterpret_cast<P *>(static_cast<uintptr_t>(wavesim::uniform_claim(static_cast<uint64_t>(reinterpret_cast<uintptr_t>(p)))));
+}
 
 NDZIP_DEV uint32_t lane_offset_here(uint32_t bytes) { return bytes; }
 
 NDZIP_DEV int fresh_copy(int x) { return x; }
 
-NDZIP_DEV int wave_uniform(int x) { return x; }  // (the caller's claim; the value is the lane's own)
+NDZIP_DEV int wave_uniform(int x) { return static_cast<int>(static_cast<uint32_t>(wavesim::uniform_claim(static_cast<uint32_t>(x)))); }  // (checked, see above)
 
 NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction scheduling only)
 

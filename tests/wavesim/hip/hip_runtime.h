@@ -54,6 +54,7 @@ uint64_t wave_exchange(uint64_t v, int src);     // every lane deposits v, gets 
 uint64_t wave_ballot(bool pred);
 uint32_t update_dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask, unsigned bank_mask, bool bound_ctrl);
 void sleep_hint();                               // s_sleep: lets other workgroups (OS threads) and fibers run
+uint64_t uniform_claim(uint64_t v);              // v_readfirstlane of a value claimed wave-uniform: aborts unless every lane passes the same
 
 struct launch_cfg {
     unsigned grid, block;

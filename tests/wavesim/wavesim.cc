@@ -71,6 +71,20 @@ struct lds_key_hash {
     size_t operator()(const lds_key &k) const { return (k.site * 0x9e3779b97f4a7c15ull) ^ (static_cast<size_t>(k.kind) << 40) ^ k.occurrence; }
 };
 
+// a wave_uniform / scalar_pointer claim: the n-th execution of one static call site by a lane between two synchronisation points
+struct claim_key {
+    uintptr_t site;
+    uint32_t occurrence;
+    bool operator==(const claim_key &o) const { return site == o.site && occurrence == o.occurrence; }
+};
+struct claim_key_hash {
+    size_t operator()(const claim_key &k) const { return (k.site * 0x9e3779b97f4a7c15ull) ^ k.occurrence; }
+};
+struct claim_value {
+    uint64_t value;
+    unsigned tid;
+};
+
 struct wave_state {
     uint64_t slot[2][64];
     unsigned arrived = 0;
@@ -78,6 +92,7 @@ struct wave_state {
     unsigned alive = 64;
     unsigned tag = op_none;
     std::unordered_map<lds_key, lds_event, lds_key_hash> lds_events;  // of the current barrier interval (profile builds only)
+    std::unordered_map<claim_key, claim_value, claim_key_hash> claims;  // uniformity claims since the wavefront last met
 };
 
 }  // namespace
@@ -93,6 +108,8 @@ struct lane_ctx {
     const char *where = "";             // what the work-item waits in (deadlock report)
     void *site = nullptr;               // return address of that call
     std::unordered_map<uint64_t, uint32_t> lds_occurrence;  // per static access: executions in the current barrier interval
+    std::unordered_map<uintptr_t, uint32_t> claim_occurrence;  // per static wave_uniform call: executions since the wavefront last met
+    bool claimed = false;
 };
 
 namespace {
@@ -122,15 +139,36 @@ void yield_to_scheduler() {
     wavesim_switch(&l->sp, l->wg->sched_sp);
 }
 
+// The lanes of wavefront `wi` have all arrived at one point of the program (a completed wave operation or barrier): the claims
+// recorded so far have been compared, and the per-call-site execution counts start again -- from here on every lane counts
+// from the same place, which is what makes "n-th execution of this call site" name the same wave-instruction in every lane.
+void reset_claims(wg_state *wg, size_t wi) {
+    wave_state &w = wg->waves[wi];
+    if (!w.claims.empty()) w.claims.clear();
+    const size_t end = std::min<size_t>(wg->lanes.size(), (wi + 1) * 64);
+    for (size_t t = wi * 64; t < end; ++t) {
+        lane_ctx &l = wg->lanes[t];
+        if (l.claimed) {
+            l.claim_occurrence.clear();
+            l.claimed = false;
+        }
+    }
+}
+void reset_all_claims(wg_state *wg) {
+    for (size_t wi = 0; wi < wg->waves.size(); ++wi) reset_claims(wg, wi);
+}
+
 void release_if_complete(wg_state *wg, wave_state *w) {
     if (w && w->alive > 0 && w->arrived == w->alive) {
         w->arrived = 0;
         w->tag = op_none;
         ++w->gen;
+        reset_claims(wg, static_cast<size_t>(w - wg->waves.data()));
     }
     if (wg->alive > 0 && wg->barrier_arrived == wg->alive) {
         wg->barrier_arrived = 0;
         ++wg->barrier_gen;
+        reset_all_claims(wg);
         if (wg->lds_traced) lds_profile_flush(wg);
     }
 }
@@ -307,6 +345,7 @@ void barrier() {
     if (++wg->barrier_arrived == wg->alive) {
         wg->barrier_arrived = 0;
         ++wg->barrier_gen;
+        reset_all_claims(wg);
         if (wg->lds_traced) lds_profile_flush(wg);
         return;
     }
@@ -335,6 +374,7 @@ const uint64_t *rendezvous(uint64_t v, unsigned tag, void *site) {
         w.arrived = 0;
         w.tag = op_none;
         ++w.gen;
+        reset_claims(wg, l->tid / 64);
     } else {
         l->wait_on = &w.gen;
         l->wait_val = gen;
@@ -399,6 +439,30 @@ uint32_t update_dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask
     }
     if (from < 0) return bound_ctrl ? 0u : old;
     return static_cast<uint32_t>(buf[from]);
+}
+
+// wave_uniform / scalar_pointer: on hardware v_readfirstlane hands the FIRST active lane's value to the whole wavefront, whatever the
+// other lanes hold -- a claim that is false for some lane computes with lane 0's value there and with the lane's own value in a
+// model that takes the claim on trust.  Here every execution of a claim is recorded per wavefront and static call site (the n-th
+// execution since the wavefront last met in a wave operation or barrier; lanes run one after the other in between) and a lane
+// that passes another value than the first one aborts the process with the call site.  Returns the first lane's value.
+uint64_t uniform_claim(uint64_t v) {
+    lane_ctx *l = g_self;
+    const uintptr_t site = reinterpret_cast<uintptr_t>(__builtin_return_address(0));
+    wave_state &w = l->wg->waves[l->tid / 64];
+    const uint32_t n = l->claim_occurrence[site]++;
+    l->claimed = true;
+    const auto ins = w.claims.try_emplace(claim_key{site, n}, claim_value{v, l->tid});
+    if (!ins.second && ins.first->second.value != v) {
+        Dl_info info{};
+        dladdr(reinterpret_cast<void *>(site), &info);
+        fprintf(stderr, "wavesim: wave_uniform / scalar_pointer claim is false: work-item %u passes 0x%llx where work-item %u of the same wavefront "
+                "passed 0x%llx (block %u, call site %s+0x%zx, execution %u since the wavefront last met)\n", l->tid,
+                static_cast<unsigned long long>(v), ins.first->second.tid, static_cast<unsigned long long>(ins.first->second.value),
+                l->wg->block_idx, info.dli_fname ? info.dli_fname : "?", static_cast<size_t>(site - reinterpret_cast<uintptr_t>(info.dli_fbase)), n);
+        abort();
+    }
+    return ins.first->second.value;
 }
 
 void sleep_hint() {
