@@ -71,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--smooth", action="store_true", help="highly compressible bookend (two low-frequency octaves)")
     ap.add_argument("--data", type=str, default="synthetic", choices=["synthetic", "random", "zeros"])
     ap.add_argument("--workgroups-per-cu", type=int, default=0, help="cap the persistent compress grid (0 = default: 4 per CU); 3 = the round-2 grid, for an A/B of the occupancy")
-    ap.add_argument("--sync-exchange", action="store_true", help="N > 1: finish the offset / header exchange before decompress (default: it runs behind the decompress launch)")
+    ap.add_argument("--overlap-exchange", action="store_true", help="N > 1: leave the offset / header exchange in flight behind the decompress launch (opt-in until it has run over RCCL on a multi-GPU node; default: compress -> exchange -> decompress, every collective waited for)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true")
@@ -410,10 +410,11 @@ def main(argv=None):
     dims = len(global_extent)
     t_dtype = torch.float32 if np_dtype == np.float32 else torch.float64
     # N > 1: the offset / header exchange (all-gather of one length per rank, base + global offsets, all-gather of the header
-    # segments: 8 x 128 KiB at N = 8) runs BEHIND the decompress launch, which decodes the rank's slab from its local offsets and
-    # needs nothing from the other ranks (ndzip_amd/sharded.py: overlap_exchange); --sync-exchange puts it between the two
-    # launches instead (compress -> exchange -> decompress, every collective waited for)
-    codec = ShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and not args.sync_exchange)
+    # segments: 8 x 128 KiB at N = 8) lies between the two launches: compress -> exchange -> decompress, every collective waited
+    # for.  --overlap-exchange lets it run BEHIND the decompress launch instead, which decodes the rank's slab from its local
+    # offsets and needs nothing from the other ranks (ndzip_amd/sharded.py: overlap_exchange) -- rehearsed over gloo on the
+    # functional model and in tests/test_hip_sharded_rccl.py, opt-in until that test has passed on a multi-GPU node.
+    codec = ShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and args.overlap_exchange)
     if args.workgroups_per_cu:
         codec.compressor.set_max_workgroups_per_cu(args.workgroups_per_cu)
     shard = codec.shard
@@ -440,15 +441,13 @@ def main(argv=None):
 
     def step(ev=None):
         # ev[0..1] bracket the compress launch (compress kernel [+ border kernel]) on the stream it runs on, ev[2..3] the
-        # decompress launch; the offset / header exchange of the N > 1 path lies between them
+        # decompress launch (recorded inside decompress(), right around the decode launch: with --overlap-exchange the rest of
+        # the exchange is enqueued behind it and is not part of the bracket); the offset / header exchange of the N > 1 path
+        # lies between ev[1] and ev[2] by default
         if mode != "decompress":
             codec.compress(local, kernel_events=(ev[0], ev[1]) if ev else None)
         if mode != "compress":
-            if ev:
-                ev[2].record()
-            codec.decompress(out)
-            if ev:
-                ev[3].record()
+            codec.decompress(out, kernel_events=(ev[2], ev[3]) if ev else None)
 
     for _ in range(args.warmup):
         step()
@@ -540,7 +539,7 @@ def main(argv=None):
                 "compression_ratio": round(ratio, 4),
                 "step": {"both": "compress then decompress", "compress": "compress only", "decompress": "decompress only"}[mode]
                         + ", inputs resident in HBM",
-                "parallelism": f"hypercube-range sharding x{world}" + ((" (RCCL all-gather of offsets + header" + (")" if args.sync_exchange else ", behind the decompress launch)")) if world > 1 else ""),
+                "parallelism": f"hypercube-range sharding x{world}" + ((" (RCCL all-gather of offsets + header" + (", behind the decompress launch)" if args.overlap_exchange else ")")) if world > 1 else ""),
             },
             "per_gpu": {},
             "roofline": roofline,

@@ -115,7 +115,7 @@ NDZIP_HIP_API int ndzip_hip_compressor_offset_header_gathered(ndzip_hip_compress
 NDZIP_HIP_API int ndzip_hip_compressor_check(ndzip_hip_compressor *c);
 
 /* No reference counterpart (a tuning / diagnosis handle): caps the workgroups per compute unit of the persistent compress grid of
- * this handle's later launches.  0 (the default) = as many as are resident (4); 1..3 launch a smaller grid -- same kernels, same
+ * this handle's later launches.  0 (the default) = as many as are resident (4); 1..3 launch a smaller grid (values up to 64 are accepted and have no effect beyond what is resident) -- same kernels, same
  * stream, bit for bit -- e.g. to measure what the 4th workgroup per CU buys, or to leave room on a GPU shared with other work. */
 NDZIP_HIP_API int ndzip_hip_compressor_set_max_workgroups_per_cu(ndzip_hip_compressor *c, int max_workgroups_per_cu);
 

@@ -131,22 +131,33 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
 
 
 TEST_VARIANT_SPIN0 = os.path.join(HERE, "_variants", "spin0.so")
+TEST_VARIANT_PLAIN = os.path.join(HERE, "_variants", "plain.so")
+TEST_VARIANTS = {  # name: extra defines
+    "spin0": ["-DNDZIP_LOOKBACK_SPIN_LIMIT=0"],
+    "plain": ["-DNDZIP_NO_EXEC_ASM", "-DNDZIP_NO_SCALAR_PINS"],
+}
 
 
 def build_test_variants(force: bool = False, verbose: bool = False) -> str:
-    """ndzip_amd/_variants/spin0.so: the same library with a look-back spin limit of 0 (any wait for a predecessor is a
-    timeout), for the GPU test of the give-up path (tests/test_hip_stress.py).  Test infrastructure; never loaded by the package."""
-    out = TEST_VARIANT_SPIN0
-    objdir = os.path.join(HERE, "_variants", "obj_spin0")
-    os.makedirs(objdir, exist_ok=True)
+    """Test infrastructure, never loaded by the package:
+    ndzip_amd/_variants/spin0.so -- the same library with a look-back spin limit of 0 (any wait for a predecessor is a timeout), for
+    the GPU test of the give-up path (tests/test_hip_stress.py);
+    ndzip_amd/_variants/plain.so -- without the hand-written EXEC-masked assembly and without the v_readfirstlane uniformity pins
+    (gfx950_lds.hpp: bisecting aids), for tools/variant_parity.py."""
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".inl"))] + [os.path.abspath(__file__)]
-    if not force and not _stale(out, deps):
-        return out
-    jobs, objs = [], []
-    for src in SOURCES:
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
-        objs.append(o)
-        jobs.append([HIPCC, *FLAGS, "-DNDZIP_LOOKBACK_SPIN_LIMIT=0", "-c", os.path.join(CSRC, src), "-o", o])
+    jobs, links = [], []
+    for name, defines in TEST_VARIANTS.items():
+        out = os.path.join(HERE, "_variants", name + ".so")
+        objdir = os.path.join(HERE, "_variants", "obj_" + name)
+        os.makedirs(objdir, exist_ok=True)
+        if not force and not _stale(out, deps):
+            continue
+        objs = []
+        for src in SOURCES:
+            o = os.path.join(objdir, src.replace(".hip", ".o"))
+            objs.append(o)
+            jobs.append([HIPCC, *FLAGS, *defines, "-c", os.path.join(CSRC, src), "-o", o])
+        links.append([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out, *objs])
 
     def run(cmd):
         if verbose:
@@ -155,10 +166,12 @@ def build_test_variants(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
 
-    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
-        list(ex.map(run, jobs))
-    run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out, *objs])
-    return out
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(run, jobs))
+    for cmd in links:
+        run(cmd)
+    return TEST_VARIANT_SPIN0
 
 
 if __name__ == "__main__":

@@ -827,22 +827,23 @@ namespace {
 // `dest` != nullptr: a compress job's stream goes there (room for `dest_capacity_words`) instead of to the buffer named at
 // submit time -- the copy happens here, when the exact length is known, so a caller that packs streams back to back
 // (ndzip_hip_chunked_compress) names the final place only now.
+// time between the slot's events, read once the job's (last) launch is known to have ended
+int slot_kernel_time(offload_slot *s, int slot, uint64_t *kernel_ns) {
+    if (!kernel_ns && !verbose()) return NDZIP_HIP_OK;
+    HIP_TRY(hipEventSynchronize(s->stop));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->start, s->stop));
+    if (kernel_ns) *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+    if (verbose()) fprintf(stderr, "[ndzip-hip][profile] slot %d total kernel time %.3fms\n", slot, static_cast<double>(ms));
+    return NDZIP_HIP_OK;
+}
+
 int offloader_wait_impl(ndzip_hip_offloader *o, int slot, void *dest, uint64_t dest_capacity_words, uint32_t *words, uint64_t *kernel_ns) {
     offload_slot *s = nullptr;
     if (int st = slot_of(o, slot, &s, false)) return st;
     const int job = s->job;
     s->job = 0;
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (kernel_ns) {
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, s->start, s->stop));
-        *kernel_ns = static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
-    }
-    if (verbose()) {
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, s->start, s->stop));
-        fprintf(stderr, "[ndzip-hip][profile] slot %d total kernel time %.3fms\n", slot, static_cast<double>(ms));
-    }
     if (job == 1) {
         uint32_t bits = 0;
         int st = check_error_word(s->comp->err, s->comp->stream, &bits);
@@ -851,14 +852,18 @@ int offloader_wait_impl(ndzip_hip_offloader *o, int slot, void *dest, uint64_t d
             if (verbose()) fprintf(stderr, "[ndzip-hip] slot %d: scan look-back timeout: relaunching once\n", slot);
             const int configured = s->comp->max_blocks_per_cu;
             s->comp->max_blocks_per_cu = 1;  // (one workgroup per CU for the retry; the slot goes back to its grid afterwards)
+            // (the slot's events move to the relaunch: the time reported for the job is that of the launch whose stream is returned)
+            HIP_TRY(hipEventRecord(s->start, s->stream));
             const int e = ndzip_hip_compressor_compress(s->comp, s->d_array, o->dims, s->extent, s->d_stream, s->d_len);
             s->comp->max_blocks_per_cu = configured;
             if (e) return e;
+            HIP_TRY(hipEventRecord(s->stop, s->stream));
             HIP_TRY(hipMemcpyAsync(s->h_len, s->d_len, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
             st = check_error_word(s->comp->err, s->comp->stream, &bits);
             if (st == NDZIP_HIP_ERR_DEVICE_FAULT) st = fail(st, g_last_error + " -- again after one relaunch");
         }
         if (st) return st;
+        if (int ts = slot_kernel_time(s, slot, kernel_ns)) return ts;
         const uint32_t len = *s->h_len;
         const size_t wb = word_bytes(o->dtype);
         if (static_cast<size_t>(len) * wb > o->stream_bytes) return fail(NDZIP_HIP_ERR_DEVICE_FAULT, "stream length exceeds bound");
@@ -870,6 +875,7 @@ int offloader_wait_impl(ndzip_hip_offloader *o, int slot, void *dest, uint64_t d
         if (words) *words = len;
     } else {
         if (int st = ndzip_hip_decompressor_check(s->decomp)) return st;
+        if (int ts = slot_kernel_time(s, slot, kernel_ns)) return ts;
         if (words) *words = s->words;
     }
     return NDZIP_HIP_OK;

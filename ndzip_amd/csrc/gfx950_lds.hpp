@@ -55,7 +55,17 @@ NDZIP_DEV char *lds_pointer(uint32_t address) {
 // A value that is the same in every lane of the wavefront (a wave index, a hypercube-of-the-tile index), as a scalar: what is
 // tested on it becomes an s_cmp and a scalar branch instead of a v_cmp into a 64-bit lane mask that has to be kept (or spilled
 // and reloaded lane by lane) for as long as the condition is used.
+//
+// Bisecting aids (never defined in the product build; ndzip_amd/build.py builds ndzip_amd/_variants/plain.so with both for
+// tools/variant_parity.py): -DNDZIP_NO_SCALAR_PINS takes every uniformity claim back -- wave_uniform / scalar_pointer return the
+// lane's own value, all addressing falls back to per-lane 64-bit pointers -- and -DNDZIP_NO_EXEC_ASM replaces the EXEC-masked
+// assembly of lds_append_nonzero by the loop it stands for.  If the product library ever disagrees with the oracle on hardware
+// and the plain variant does not, the fault is in one of these two mechanisms and not in the algorithm.
+#ifdef NDZIP_NO_SCALAR_PINS
+NDZIP_DEV int wave_uniform(int x) { return x; }
+#else
 NDZIP_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+#endif
 
 // The same value, but nothing derived from it is loop-invariant as far as the optimiser can tell: predicates and wave indices
 // computed from this copy of the work-item id are re-derived (a compare, a v_readfirstlane + shift) where they are used instead of
@@ -73,6 +83,9 @@ NDZIP_DEV int fresh_copy(int x) {
 // (`p` points to GLOBAL memory: the integer round trip would otherwise leave a generic pointer, i.e. flat_ accesses.)
 template<typename P>
 NDZIP_DEV P *scalar_pointer(P *p) {
+#ifdef NDZIP_NO_SCALAR_PINS
+    return p;
+#endif
     // (v_readfirstlane folds away when the compiler can prove the value uniform, and makes the claim true where it cannot: an
     // "s" operand fed from a VGPR is a back-end error, not a copy)
     using global_p = __attribute__((address_space(1))) P;
@@ -169,6 +182,16 @@ NDZIP_DEV vec16 global_load16_block(const void *p) { return global_load16_once(p
     "v_cmpx_ne_u32_e32 vcc, 0, %[w" #n "]\n\tds_write_b32 %[a], %[w" #n "]\n\tv_add_u32_e32 %[a], 4, %[a]\n\ts_mov_b64 exec, %[full]\n\t"
 #define NDZIP_APPEND8 NDZIP_APPEND1(0) NDZIP_APPEND1(1) NDZIP_APPEND1(2) NDZIP_APPEND1(3) NDZIP_APPEND1(4) NDZIP_APPEND1(5) NDZIP_APPEND1(6) NDZIP_APPEND1(7)
 NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
+#ifdef NDZIP_NO_EXEC_ASM
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (w[i] != 0) {
+            *reinterpret_cast<uint32_t *>(lds_pointer(a)) = w[i];
+            a += 4;
+        }
+    }
+    return a;
+#endif
     unsigned long long full;
     asm volatile("s_mov_b64 %0, exec" : "=s"(full));
 #pragma unroll

@@ -228,18 +228,22 @@ class ShardedCodec:
             self._lengths_pending = None
             self._gather_headers()
 
-    def decompress(self, local_out) -> None:
+    def decompress(self, local_out, kernel_events=None) -> None:
         """Decode this rank's slab from (its header entries with global offsets, its base, its resident body).  The entries
         are header_local after globalise() == header_global[hc_begin:hc_end]; the base stays on the device (`base32` == the
         previous shard's last header entry).  No collective and no dependence on the header all-gather."""
         sh = self.shard
-        if self._lengths_pending is not None:
-            # the exchange of the last compress() is still at its first step: header_local holds LOCAL offsets (base 0) -- decode
-            # from those, then let the exchange continue behind the decode kernel
-            self.decompressor.decompress_split(self.header_local, None, self.body, local_out, sh.extent)
-            self._complete_exchange()
-            return
-        self.decompressor.decompress_split(self.header_local, self.base32, self.body, local_out, sh.extent)
+        # kernel_events: optional (start, stop) pair recorded tightly around the decode launch -- what follows it on the stream in
+        # the overlapped mode (the wait for the length all-gather, the globalise kernel) is not the decode kernel's time
+        pending = self._lengths_pending is not None
+        if kernel_events:
+            kernel_events[0].record()
+        # (pending: the exchange of the last compress() is still at its first step: header_local holds LOCAL offsets, base 0)
+        self.decompressor.decompress_split(self.header_local, None if pending else self.base32, self.body, local_out, sh.extent)
+        if kernel_events:
+            kernel_events[1].record()
+        if pending:
+            self._complete_exchange()  # ... and continues behind the decode kernel
 
     def check(self) -> None:
         self.finish()

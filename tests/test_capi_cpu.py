@@ -253,3 +253,66 @@ def test_exec_masked_plane_compaction_has_the_shape_it_was_written_in(tmp_path):
         assert rs.group(1) == saved
         if n % 8 == 7:   # end of an asm statement
             assert ins[i + 4] == "s_nop 1", ins[i:i + 6]
+
+
+def test_exec_masked_plane_compaction_executes_correctly_under_any_entry_mask(tmp_path):
+    """The model replaces lds_append_nonzero by a C++ loop, so nothing in the CPU suite ran the assembly itself.  This does: every
+    32-plane sequence found in the BUILT code object (from the save of EXEC to the last s_nop) is interpreted for 64 lanes
+    (tests/gfx9_interp.py: v_cmpx_ne_u32 / ds_write_b32 / v_add_u32 / s_mov_b64 / s_nop, anything else inside is an error) under
+    random entry EXEC masks -- the sequence is entered from a per-lane branch -- and random plane words, and compared with the
+    loop it replaces: LDS contents, the address behind the last word, untouched inactive lanes, EXEC restored."""
+    import re
+
+    import numpy as np
+
+    from tests import gfx9_interp as gi
+
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    ins = gi.disassemble(hip.LIB_PATH, str(tmp_path))
+    heads = []
+    for i, s in enumerate(ins):
+        m = re.fullmatch(r"s_mov_b64 (s\[\d+:\d+\]), exec", s)
+        if m and any(x.startswith("v_cmpx_ne_u32") for x in ins[i + 1:i + 4]):
+            heads.append((i, m.group(1)))
+    assert len(heads) >= 13, len(heads)  # 7 compress_kernel_db instantiations + 6 f32 encode stage kernels
+    rng = np.random.default_rng(20260929)
+    for n, (start, saved) in enumerate(heads):
+        # the sequence: up to and including the 4th "s_nop 1" that closes an asm statement
+        end, closes = start, 0
+        while closes < 4:
+            end += 1
+            if ins[end] == "s_nop 1" and ins[end - 1].startswith("s_mov_b64 exec"):
+                closes += 1
+        seq = ins[start:end + 1]
+        words = [re.fullmatch(r"v_cmpx_ne_u32_e32 vcc, 0, (v\d+)", s).group(1) for s in seq if s.startswith("v_cmpx")]
+        addr = re.fullmatch(r"ds_write_b32 (v\d+), v\d+", next(s for s in seq if s.startswith("ds_write"))).group(1)
+        assert len(words) == 32 and len(set(words)) == 32 and addr not in words
+        for case in range(6 if n < 3 else 2):
+            w = gi.Wave()
+            entry = [gi.MASK64, 1, 0, 0xAAAAAAAA55555555][case] if case < 4 else int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))
+            w.exec = entry
+            density = [0.6, 1.0, 0.5, 0.0, 0.3, 0.9][case % 6]
+            planes = rng.integers(1, 1 << 32, size=(32, 64), dtype=np.uint64).astype(np.uint32)
+            planes[rng.random((32, 64)) >= density] = 0
+            for i, reg in enumerate(words):
+                w.v[reg] = planes[i].copy()
+            a0 = (np.arange(64, dtype=np.uint32) * 160 + rng.integers(0, 8, size=64).astype(np.uint32) * 4).astype(np.uint32)
+            w.v[addr] = a0.copy()
+            for s in seq:
+                w.step(s)
+            assert w.exec == entry, (n, case, hex(w.exec), hex(entry))
+            want = np.zeros_like(w.lds)
+            touched = np.zeros_like(w.lds_written)
+            for lane in range(64):
+                a = int(a0[lane])
+                if (entry >> lane) & 1:
+                    for i in range(32):
+                        if planes[i, lane]:
+                            want[a // 4] = planes[i, lane]
+                            touched[a // 4] = True
+                            a += 4
+                assert int(w.v[addr][lane]) == a, (n, case, lane)
+                for i, reg in enumerate(words):
+                    assert int(w.v[reg][lane]) == int(planes[i, lane])
+            assert np.array_equal(w.lds_written, touched) and np.array_equal(w.lds, want), (n, case)
