@@ -409,9 +409,11 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     uint32_t planes[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) planes[j] = 0;
-    for (;;) {
-        const bool have_cur = tile < ntiles;
-        if (!have_cur && !have_prev) break;
+    // The loop runs while the workgroup has a tile to ENCODE; the tile it encoded last is written out behind the loop (the drain
+    // used to be one more trip through the loop with everything but the write-out switched off: three barriers, the origin
+    // arithmetic and eight clamped prefetch loads of a tile nobody needed, per workgroup and launch -- and an `if (have_cur)`
+    // around every phase of every iteration).
+    while (tile < ntiles) {
         // wave index, lane and the single-lane predicates of this iteration come from a fresh copy of the work-item id
         // (gfx950_lds.hpp: fresh_copy): re-derived here, not carried round the loop as lane masks; addresses keep using `tid` / `t`
         const int tid_i = fresh_copy(tid);
@@ -419,13 +421,11 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         const bool first_of_tile = tid_i == 0, first_of_hc = (tid_i & (threads_per_hc - 1)) == 0;
         const int t_i = db_cfg<T, Dims, Paired>::rederive_lane_addresses ? (tid_i & (threads_per_hc - 1)) : t;
         const uint32_t hc = tile * K + grp;
-        const bool active = have_cur && hc < gg.nhc;
-        if (have_cur) {
-            if constexpr (Paired) {
-                stage_pair_regs(pre, smem, C::cube_stride, tid);  // (an even hypercube count: both cubes of a tile exist)
-            } else {
-                if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t_i);
-            }
+        const bool active = hc < gg.nhc;
+        if constexpr (Paired) {
+            stage_pair_regs(pre, smem, C::cube_stride, tid);  // (an even hypercube count: both cubes of a tile exist)
+        } else {
+            if (active) stage_hypercube_regs<W, Aligned>(pre, cube, t_i);
         }
         // The previous tile's look-back window is read BEHIND the staging, not in front of it: the staging's wait for the
         // last prefetched vector is an s_waitcnt vmcnt(0) (gfx9 counts loads and stores in one in-order counter, and the
@@ -436,7 +436,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         lookback_windows window{};
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
-        const uint32_t next_tile = have_cur ? tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 1]))), cls, num_classes) : tile;
+        const uint32_t next_tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 1]))), cls, num_classes);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t next_hc = Paired ? next_tile * K : next_tile * K + grp;
         if (next_hc >= gg.nhc) next_hc = Paired ? gg.nhc - K : gg.nhc - 1;
@@ -449,30 +449,25 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         }
         __builtin_amdgcn_sched_barrier(0);
         W r[vals_per_thread];
-        uint32_t head = 0, count = 0, incl = 0;
-        if (have_cur) {
-            stencil_residuals<T, Dims>(cube, zero, t_i, r);
-            head = chunk_head32(r);
-            count = active ? static_cast<uint32_t>(__builtin_popcount(head)) : 0u;
-            incl = wave_inclusive_scan(count, lane);
-            if (lane == 63) misc[wave] = incl;
-        }
+        stencil_residuals<T, Dims>(cube, zero, t_i, r);
+        const uint32_t head = chunk_head32(r);
+        const uint32_t count = active ? static_cast<uint32_t>(__builtin_popcount(head)) : 0u;
+        const uint32_t incl = wave_inclusive_scan(count, lane);
+        if (lane == 63) misc[wave] = incl;
         __syncthreads();  // B2: all stencil reads done (staging region reusable), wave totals known
-        uint32_t run_start = 0, aggregate = 0, my_len = 0, chunk_excl = 0;
-        if (have_cur) {
+        uint32_t run_start = 0, aggregate = 0, my_len = 0;
 #pragma unroll
-            for (int g = 0; g < K; ++g) {
-                // (wave totals as scalars: the tile's lengths, and with them the copy-out's case analysis, are scalar code, and
-                // the previous tile's aggregate / run start / length are carried round the loop in SGPRs, not VGPRs)
-                const uint32_t len_g = tile * K + g < gg.nhc ? P::head_words + static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * g])))
-                                + static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * g + 1]))) : 0u;
-                if (g < grp) run_start += len_g;
-                if (g == grp) my_len = len_g;
-                aggregate += len_g;
-            }
-            chunk_excl = ((wave & 1) ? static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * grp]))) : 0u) + incl - count;
-            if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
+        for (int g = 0; g < K; ++g) {
+            // (wave totals as scalars: the tile's lengths, and with them the copy-out's case analysis, are scalar code, and
+            // the previous tile's aggregate / run start / length are carried round the loop in SGPRs, not VGPRs)
+            const uint32_t len_g = tile * K + g < gg.nhc ? P::head_words + static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * g])))
+                            + static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * g + 1]))) : 0u;
+            if (g < grp) run_start += len_g;
+            if (g == grp) my_len = len_g;
+            aggregate += len_g;
         }
+        const uint32_t chunk_excl = ((wave & 1) ? static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * grp]))) : 0u) + incl - count;
+        if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
         // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
         // live around the whole loop.
@@ -490,11 +485,9 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             }
         }
         // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
-        if (have_cur) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) planes[j] = r[j];
-            transpose32(planes);
-        }
+        for (int j = 0; j < 32; ++j) planes[j] = r[j];
+        transpose32(planes);
         __builtin_amdgcn_sched_barrier(0);
         // The previous tile's prefix, as the LAST thing wavefront 0 does before B3: its predecessors (which may lag by
         // a good part of an iteration) have had the most time to publish, and its own late prefetch, which hipcc's
@@ -518,12 +511,10 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
             const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
             copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
             if (prev_active && first_of_hc) header[prev_hc] = prefix + prev_run_start + prev_my_len;  // offset_after(hc), common.hh:342-347
-            // the last tile ends the body (store_stream_length, cuda_codec.inl:507-511)
-            if (first_of_tile && prev_tile == ntiles - 1) store_stream_length(out_len, len_extra + prefix + prev_aggregate);
         }
         if (draw) misc[NW + 1] = ticket_after_next;
         __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them; next ticket in LDS
-        have_prev = have_cur;
+        have_prev = true;
         prev_tile = tile;
         prev_aggregate = aggregate;
         prev_run_start = run_start;
@@ -533,6 +524,29 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         prev_active = active;
         prev_hc = hc;
         tile = next_tile;
+    }
+    // Drain: the tile encoded last is still in registers.  Plane writes, look-back (a window read now: its predecessors have had
+    // the whole last iteration), one barrier, copy-out.  A workgroup that never drew a tile (a grid larger than the tile count
+    // cannot happen -- launch_persistent clamps it -- but a ticket can lose the race for the last tiles) has nothing to do.
+    if (have_prev) {
+        const int tid_i = fresh_copy(tid);
+        const int lane = tid_i & 63, wave = wave_uniform(tid_i >> 6);
+        const bool first_of_tile = tid_i == 0, first_of_hc = (tid_i & (threads_per_hc - 1)) == 0;
+        const int t_i = db_cfg<T, Dims, Paired>::rederive_lane_addresses ? (tid_i & (threads_per_hc - 1)) : t;
+        if (prev_active) write_planes32(tile_run + prev_run_start, prev_run_start, t_i, prev_head, prev_chunk_excl, planes);
+        if (wave == 0) {
+            const uint32_t exclusive = resolve_exclusive_prefix(desc, prev_tile, prev_aggregate, err, lane);
+            if (first_of_tile) misc[NW] = exclusive;
+        }
+        lds_append_complete();
+        __syncthreads();
+        const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
+        // (tid_i, not tid: nothing derived from the work-item id is kept alive across the loop for the drain's sake)
+        copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid_i);
+        if (prev_active && first_of_hc) header[prev_hc] = prefix + prev_run_start + prev_my_len;  // offset_after(hc), common.hh:342-347
+        // the last tile ends the body (store_stream_length, cuda_codec.inl:507-511): tiles are drawn in increasing order within a
+        // class, so the last tile is always some workgroup's LAST tile -- the length is stored here and nowhere else
+        if (first_of_tile && prev_tile == ntiles - 1) store_stream_length(out_len, len_extra + prefix + prev_aggregate);
     }
     // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
     // visible); the descriptors need no clearing (epoch).
@@ -596,53 +610,47 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     uint32_t planes[E::planes_per_lane];
 #pragma unroll
     for (int j = 0; j < E::planes_per_lane; ++j) planes[j] = 0;
-    for (;;) {
-        const bool have_cur = tile < ntiles;
-        if (!have_cur && !have_prev) break;
+    // (the loop runs while there is a tile to encode; the last one is written out behind it: see compress_kernel_db)
+    while (tile < ntiles) {
         // (wave index, lane and the single-lane predicate re-derived per iteration: see compress_kernel_db.  Here the LDS
         // addresses of the staging, the stencil's row pointers and the coding's lane roles are re-derived from it too: ~30 VALU
         // instructions per iteration instead of a dozen loop-invariant VGPRs, which is what fits the 1D and 2D kernel into 128)
         const int tid_i = fresh_copy(tid);
         const int lane = tid_i & 63, wave = wave_uniform(tid_i >> 6);
         const bool first_of_tile = tid_i == 0;
-        if (have_cur) wide::stage_regs<W>(pre, cube, tid_i);
+        wide::stage_regs<W>(pre, cube, tid_i);
         lookback_windows window{};  // (behind the staging: see compress_kernel_db)
         if (have_prev && wave == 0) lookback_issue(desc, prev_tile, lane, window);
         __syncthreads();  // B1: cube staged (the next ticket has been in misc[NW + 1] since before the last B4)
-        const uint32_t next_tile = have_cur ? tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 1]))), cls, num_classes) : tile;
+        const uint32_t next_tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 1]))), cls, num_classes);
         __builtin_amdgcn_sched_barrier(0);
         const uint64_t next_origin = hc_origin<Dims>(gg, next_tile < ntiles ? next_tile : ntiles - 1);
         wide::load_regs<W, Dims, Aligned, 0, early_vectors>(in, gg, next_origin, t, pre);
         __builtin_amdgcn_sched_barrier(0);
         W r[wide::vals];
-        uint32_t head_a = 0, head_b = 0, count = 0, incl = 0;
-        if (have_cur) {
-            wide::stencil<W, Dims>(cube, zero, tid_i, r);
-            count = E::head_and_count(r, head_a, head_b);
-            // (the lanes of a chunk end up with the same inclusive value: only the first one feeds the scan)
-            incl = wave_inclusive_scan((tid_i & (E::lanes_per_chunk - 1)) == 0 ? count : 0u, lane);
-            if (lane == 63) misc[wave] = incl;
-        }
+        uint32_t head_a = 0, head_b = 0;
+        wide::stencil<W, Dims>(cube, zero, tid_i, r);
+        const uint32_t count = E::head_and_count(r, head_a, head_b);
+        // (the lanes of a chunk end up with the same inclusive value: only the first one feeds the scan)
+        const uint32_t incl = wave_inclusive_scan((tid_i & (E::lanes_per_chunk - 1)) == 0 ? count : 0u, lane);
+        if (lane == 63) misc[wave] = incl;
         __syncthreads();  // B2: all stencil reads done (staging region reusable), wave totals known
-        uint32_t aggregate = 0, chunk_excl = 0;
-        if (have_cur) {
-            aggregate = E::head_words;
+        uint32_t aggregate = E::head_words, chunk_excl = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const uint32_t total = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[w])));  // (scalars: see compress_kernel_db)
-                aggregate += total;
-                if (w < wave) chunk_excl += total;
-            }
-            chunk_excl += incl - count;
-            if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t total = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[w])));  // (scalars: see compress_kernel_db)
+            aggregate += total;
+            if (w < wave) chunk_excl += total;
         }
+        chunk_excl += incl - count;
+        if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
         __builtin_amdgcn_sched_barrier(0);
         wide::load_regs<W, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
         __builtin_amdgcn_sched_barrier(0);
         // the previous tile's planes leave the registers: compact them into the (now free) staging region
         if (have_prev) E::write(prev_held, planes, run32, tid_i);
         // bit-plane transpose of the current tile, in registers; it stays there until the next iteration
-        if (have_cur) E::transpose(r, tid_i, planes);
+        E::transpose(r, tid_i, planes);
         __builtin_amdgcn_sched_barrier(0);
         if (have_prev && wave == 0) {
             const uint32_t exclusive = resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
@@ -655,22 +663,38 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         if (have_prev) {
             const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
             copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
-            if (first_of_tile) {
-                header[prev_tile] = prefix + prev_aggregate;  // offset_after(hc), common.hh:342-347
-                if (prev_tile == gg.nhc - 1) {
-                    store_stream_length(out_len, len_extra + prefix + prev_aggregate);
-                    // zero the header pad of 64-bit streams with an odd hypercube count (cuda_codec.inl:446-452)
-                    if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
-                }
-            }
+            if (first_of_tile) header[prev_tile] = prefix + prev_aggregate;  // offset_after(hc), common.hh:342-347
         }
         if (draw) misc[NW + 1] = ticket_after_next;
         __syncthreads();  // B4: copy-out has read the run before the next tile is staged over it; next ticket in LDS
-        have_prev = have_cur;
+        have_prev = true;
         prev_tile = tile;
         prev_aggregate = aggregate;
         prev_held = E::hold(tid_i, head_a, head_b, E::head_words + chunk_excl);
         tile = next_tile;
+    }
+    // drain: the tile encoded last is still in registers (see compress_kernel_db)
+    if (have_prev) {
+        const int tid_i = fresh_copy(tid);
+        const int lane = tid_i & 63, wave = wave_uniform(tid_i >> 6);
+        const bool first_of_tile = tid_i == 0;
+        E::write(prev_held, planes, run32, tid_i);
+        if (wave == 0) {
+            const uint32_t exclusive = resolve_exclusive_prefix(desc, prev_tile, prev_aggregate, err, lane);
+            if (first_of_tile) misc[NW] = exclusive;
+        }
+        __syncthreads();
+        const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
+        copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid_i);
+        if (first_of_tile) {
+            header[prev_tile] = prefix + prev_aggregate;  // offset_after(hc), common.hh:342-347
+            // (the last hypercube is always some workgroup's last tile: the stream length is stored here and nowhere else)
+            if (prev_tile == gg.nhc - 1) {
+                store_stream_length(out_len, len_extra + prefix + prev_aggregate);
+                // zero the header pad of 64-bit streams with an odd hypercube count (cuda_codec.inl:446-452)
+                if (sizeof(W) == 8 && (gg.nhc & 1u)) header[gg.nhc] = 0;
+            }
+        }
     }
     release_tickets(tickets, num_classes, tid, err, out_len);
 }
