@@ -151,6 +151,12 @@ NDZIP_HIP_API int ndzip_hip_decompressor_decompress_split(ndzip_hip_decompressor
 NDZIP_HIP_API int ndzip_hip_decompressor_decompress_split_bounded(ndzip_hip_decompressor *d, const uint32_t *d_header,
         const uint32_t *d_header_base, const void *d_body, uint32_t body_words, void *d_out, int dims, const uint32_t *extent);
 
+/* Tuning / A-B switch, no reference counterpart (the reference fixes 512 threads per 64-bit hypercube,
+ * src/ndzip/gpu_common.hh:38-43): work-items the kernel of a 64-bit profile decodes one hypercube with -- 0 = the library's
+ * default (256: decompress_kernel_wide, 4 wavefronts per SIMD), 128 (decompress_kernel, the mapping of the 32-bit profiles,
+ * 2 wavefronts per SIMD) or 256.  Both produce the same bits.  No effect on 32-bit profiles. */
+NDZIP_HIP_API int ndzip_hip_decompressor_set_f64_work_items(ndzip_hip_decompressor *d, int work_items_per_hypercube);
+
 /* Reads and clears the handle's sticky device error word (corrupt header entries); synchronises the handle's stream. */
 NDZIP_HIP_API int ndzip_hip_decompressor_check(ndzip_hip_decompressor *d);
 NDZIP_HIP_API int ndzip_hip_decompressor_destroy(ndzip_hip_decompressor *d);
@@ -245,6 +251,7 @@ NDZIP_HIP_API int ndzip_hip_chunked_decompress(int dtype, int dims, const uint64
  *        2 decode an encoded run -> 4096 residual words
  *        3 inverse transform of 4096 residual words -> hypercube `hc` of the device array `d_out`
  *        4 / 5 32x32 bit transposes of `n` blocks of 32 uint32 (v_perm network / shift-mask network)
+ *        8 / 9 stages 2 / 3 through the 256-work-item decoder of the 64-bit profiles (dtype NDZIP_HIP_F64 only)
  *        6 the wave64 scan and sum (DPP): `n` uint32 (a multiple of 64) -> per wavefront the inclusive prefix sums, then
  *          n / 64 wave totals behind them (`d_out` holds n + n / 64 words) */
 NDZIP_HIP_API int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in,

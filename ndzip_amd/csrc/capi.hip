@@ -224,6 +224,7 @@ struct ndzip_hip_decompressor {
     hipStream_t stream;
     uint32_t *err;
     int num_xcds;
+    int f64_work_items = 0;  // 0 = default mapping of the 64-bit decoder (256 work-items per hypercube); 128 / 256 = an explicit choice
 };
 
 extern "C" {
@@ -444,6 +445,7 @@ static int decompress_common(ndzip_hip_decompressor *d, const uint32_t *d_header
     a.aligned = is_aligned(d->dtype, gg, d_out);
     a.body_words = body_words;
     a.num_xcds = d->num_xcds;
+    a.f64_work_items = d->f64_work_items;
     if (verbose()) fprintf(stderr, "[ndzip-hip] decompress: %u hypercubes, %llu border elements\n", gg.nhc,
             static_cast<unsigned long long>(border_count(gg)));
     if (gg.nhc > 0) {
@@ -479,6 +481,15 @@ int ndzip_hip_decompressor_decompress_bounded(ndzip_hip_decompressor *d, const v
     const void *body = static_cast<const char *>(d_stream) + static_cast<size_t>(hw) * word_bytes(d->dtype);
     const uint32_t body_words = stream_length_words == 0xffffffffu ? 0xffffffffu : stream_length_words - hw;
     return decompress_common(d, static_cast<const uint32_t *>(d_stream), nullptr, body, body_words, d_out, dims, extent);
+}
+
+int ndzip_hip_decompressor_set_f64_work_items(ndzip_hip_decompressor *d, int work_items_per_hypercube) {
+    if (!d) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle");
+    if (work_items_per_hypercube != 0 && work_items_per_hypercube != 128 && work_items_per_hypercube != 256) {
+        return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "work-items per 64-bit hypercube: 0 (default), 128 or 256");
+    }
+    d->f64_work_items = work_items_per_hypercube;
+    return NDZIP_HIP_OK;
 }
 
 int ndzip_hip_decompressor_check(ndzip_hip_decompressor *d) {
@@ -1053,9 +1064,13 @@ int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent
     if (int s = ensure_device(nullptr)) return s;
     uint32_t one[3] = {side_for_dims(dims), side_for_dims(dims), side_for_dims(dims)};
     const grid_geom gg = make_geom(dims, extent ? extent : one);
-    const void *array = stage == debug_forward_transform ? d_in : stage == debug_inverse_transform ? d_out : nullptr;
+    const bool inverse = stage == debug_inverse_transform || stage == debug_inverse_transform_wide;
+    const void *array = stage == debug_forward_transform ? d_in : inverse ? d_out : nullptr;
     const bool aligned = array ? is_aligned(dtype, gg, array) : true;
-    if ((stage == debug_forward_transform || stage == debug_inverse_transform) && hc >= gg.nhc) {
+    if ((stage == debug_decode_residuals_wide || stage == debug_inverse_transform_wide) && dtype != NDZIP_HIP_F64) {
+        return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "stages 8 / 9 are the 256-work-item decoder of 64-bit profiles");
+    }
+    if ((stage == debug_forward_transform || inverse) && hc >= gg.nhc) {
         return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "hypercube index out of range");
     }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);

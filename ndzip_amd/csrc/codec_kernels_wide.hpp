@@ -245,5 +245,293 @@ struct coding<uint64_t> {
     }
 };
 
+
+// =========================================================================================================================
+// f64 DECODE with 256 work-items per hypercube (the mirror image of the encoder above; decompress_kernel_wide).
+//
+// Why: the 128-work-item decoder of codec_kernels.hpp carries, per f64 work-item, 64 plane halves + 64 keep-masks through
+// the gather and 32 x 64-bit values through the inverse transform: 146 VGPRs, and with 35 KB of LDS per hypercube and two
+// wavefronts per workgroup a CU holds 4 workgroups = 2 wavefronts per SIMD -- nothing to cover an LDS or memory round trip
+// with.  Here a work-item gathers 32 plane dwords (one 32x32 transpose instead of two) and carries 16 values: half the
+// registers per lane, the same LDS per hypercube, twice the wavefronts per CU (4 per SIMD).
+//
+// Lane roles inside a chunk's quad q = t % 4 (exactly what coding<uint64_t>::hold gave the encoder's lanes): q & 1 picks the
+// planes -- 0..31 (head_hi) or 32..63 (head_lo) --, q & 2 the dword of the 64-bit plane word -- lanes 0, 1 the HIGH dword
+// (values 0..31 of the chunk), lanes 2, 3 the LOW dword (values 32..63).
+//
+// Reference behaviour restated (not its structure): read_transposed_chunks / zero-word expansion + inverse bit transpose
+// (src/ndzip/cuda_codec.inl:278-365, cpu_codec.inl:561-578), complement_negative (common.hh:442-449),
+// inverse_block_transform (cuda_codec.inl:129-183, common.hh:493-535), rotate_right_1 + store_hypercube
+// (common.hh:436-440, cuda_codec.inl:58-65).
+// =========================================================================================================================
+
+// LDS of decompress_kernel_wide: [region_bytes: the encoded run, later the decoded values (value_layout below)]
+// [4 x uint32 wave totals][4 x uint64 1D wave carries][2D: 3 x 64 column totals of the row quarters].  No zero block.
+template<int Dims>
+struct decode_layout {
+    // run + worst misalignment + the plane word read behind it, in whole 128-byte swizzle blocks (>= the 32 KiB of values)
+    static constexpr uint32_t region_bytes = ((hc_size + hc_size / 64 + 1) * 8 + 16 + 127) / 128 * 128 + 128;
+    static_assert(region_bytes >= hc_size * 8, "the decoded values fit the region");
+    static constexpr uint32_t totals_offset = region_bytes;            // uint32[4]
+    static constexpr uint32_t carries_offset = totals_offset + 16;     // uint64[4]
+    static constexpr uint32_t columns_offset = carries_offset + 32;    // uint64[3 * 64] (2D only)
+    static constexpr uint32_t smem_bytes = columns_offset + (Dims == 2 ? 3 * 64 * 8 : 0) + 16;
+};
+
+// Where the DECODED values wait between the in-register sums and the store pass: unpadded, 128-byte row r = values
+// [16 r, 16 r + 16) with its 16-byte slot s at slot s ^ (r & 7).  Checked against the guide's LDS table (lane groups and bank
+// windows per access width; tools/lds_profile.py prices it at 1.00x):
+//   * the writer (work-item t = row t, eight ds_write_b128): served 8 consecutive lanes at a time over a 128-byte window -- the 8
+//     rows of a group put slot i at i ^ 0..7, all different (padded like lds_layout, 16 bytes per 32 values, lanes 2m / 2m + 1
+//     met in one slot: every write a 2-way conflict; the pad per row of wide::layout avoids that but breaks the reads below);
+//   * the 3D reader (lane = (y, x), ds_read_b64 of row 16 z + y): 32 lanes = rows y, y + 1 = the two halves of a 256-byte
+//     window, 16 lanes each over the row's 8 slots x 2;  the 2D reader (lane = column x): 32 lanes = two quarter rows, likewise;
+//   * the 1D reader (lane t reads slot t % 8 of row t / 8 + 32 i, ds_read_b128): the table's 16-lane groups {0-3, 12-15, 20-27}
+//     ... see rows r, r + 1, r + 2, r + 3 at slots {0-3}, {4-7} ^ 1, {4-7} ^ 2, {0-3} ^ 3 in alternating halves: 16 different.
+// On LDS byte ADDRESSES as integers (gfx950_lds.hpp), like run_layout: one v_xor per access whose slot is not a constant.
+struct value_layout {
+    // LDS address of slot 0 of row `r` with the row's swizzle folded in: the 16-byte slot s lives at  row_base(r) ^ (16 s)
+    NDZIP_DEV static uint32_t row_base(uint32_t region, uint32_t r) { return (region + 128u * r) | (16u * (r & 7u)); }
+};
+
+// phase 1: encoded run (run_layout<uint64_t>, `run_off` bytes into `region`) -> the 16 residuals of work-item t, with
+// complement_negative already undone (in the plane domain: every plane below the sign plane XOR the sign plane).
+// Contains one __syncthreads().
+NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *totals, int t, uint64_t (&r)[vals]) {
+    using R = run_layout<uint64_t>;
+    constexpr uint32_t head_words = hc_size / 64;
+    const int lane = t & 63, wave = wave_uniform(t >> 6);
+    const int q = t & 3;
+    const bool odd = (q & 1) != 0;
+    const uint32_t c = static_cast<uint32_t>(t) >> 2;
+    const char *run = region + run_off;
+    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(run);
+    // (the four lanes of a chunk read the same two head dwords: an LDS broadcast)
+    const uint32_t head_lo = *R::ptr(in32 + 2 * c), head_hi = *R::ptr(in32 + 2 * c + 1);
+    const uint32_t cnt_hi = static_cast<uint32_t>(__builtin_popcount(head_hi));
+    const uint32_t cnt = cnt_hi + static_cast<uint32_t>(__builtin_popcount(head_lo));
+    // (the lanes of a chunk end up with the same inclusive value: only the first one feeds the scan)
+    const uint32_t incl = wave_inclusive_scan(q == 0 ? cnt : 0u, lane);
+    if (lane == 63) totals[wave] = incl;
+    __syncthreads();
+    uint32_t base = head_words + incl - cnt;
+#pragma unroll
+    for (int w = 0; w < threads / 64 - 1; ++w) {
+        if (w < wave) base += totals[w];
+    }
+    const uint32_t first = lds_address(run) + 8 * base;   // linear LDS address of the chunk's first plane word
+    const uint32_t mine = odd ? head_lo : head_hi;        // head bits of this lane's 32 planes, MSB = its first plane
+    const uint32_t half = (q & 2) ? 0u : 4u;              // byte of this lane's dword inside a plane word
+    uint32_t w[32];
+    uint32_t sign;  // this lane's dword of the chunk's sign plane (plane 0: held by the even lane of the pair)
+    // Every chunk of the wavefront keeps all 64 planes at a 16-byte aligned position (incompressible data; all chunks are then
+    // 512 bytes long, so they are aligned together): a lane's 32 plane dwords are 16 whole slots of the swizzled run -- 16
+    // ds_read_b128 instead of 32 word reads at a lane stride of 512 bytes within a quad's 256, which the swizzle spreads over
+    // two slot positions only.  Wave-uniform on purpose: everything else pays one ballot and a scalar branch for it.
+    if (__ballot(!((head_lo & head_hi) == 0xffffffffu && (first & 15u) == 0)) == 0) {
+        const uint32_t a = first + (odd ? 256u : 0u);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const vec16 v = lds_read16(lds_pointer(R::at(a + 16u * static_cast<uint32_t>(k))));
+            w[2 * k] = half ? v.w[1] : v.w[0];
+            w[2 * k + 1] = half ? v.w[3] : v.w[2];
+        }
+        const uint32_t pair0 = pair_swap(w[0]);  // (every lane executes the swap: a DPP move reads lanes that must be active)
+        sign = odd ? pair0 : w[0];
+        w[0] ^= odd ? sign : 0u;
+#pragma unroll
+        for (int i = 1; i < 32; ++i) w[i] ^= sign;
+    } else {
+        // walk this lane's kept planes from the LAST one back to the first (see decode_residuals in codec_kernels.hpp): the byte
+        // address steps down one 64-bit plane word per set head bit, the dword under it is read speculatively (inside the run, or
+        // the 8 bytes behind it, which the staging region holds) and kept iff the bit is set
+        uint32_t p = first + 8 * (odd ? cnt : cnt_hi) + half;  // linear LDS address; the dword sits at R::at(p)
+        int32_t kept[32];
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+            kept[i] = opaque_vgpr(static_cast<int32_t>(mine << i) >> 31);
+            p = static_cast<uint32_t>(opaque_vgpr(static_cast<int32_t>(p + 8 * kept[i])));  // (one v_lshl_add_u32; not a running count)
+            w[i] = *reinterpret_cast<const uint32_t *>(lds_pointer(R::at(p)));
+        }
+        lds_reads_issued_before_use(w);
+        // keep-mask and plane-domain complement fused: (word & kept) ^ sign plane = one v_bitop3_b32 per plane dword.  The odd
+        // lane's planes 32..63 are all below the sign plane, which its pair's even lane holds as plane 0.
+        const uint32_t own0 = w[0] & static_cast<uint32_t>(kept[0]);
+        const uint32_t pair0 = pair_swap(own0);  // (every lane executes the swap: a DPP move reads lanes that must be active)
+        sign = odd ? pair0 : own0;
+        w[0] = own0 ^ (odd ? sign : 0u);
+#pragma unroll
+        for (int i = 1; i < 32; ++i) w[i] = (w[i] & static_cast<uint32_t>(kept[i])) ^ sign;
+    }
+    // inverse of coding<uint64_t>::transpose: one 32x32 transpose per lane -- the even lane then holds the HIGH dwords of the
+    // pair's 32 values, the odd lane the LOW dwords -- and the pair swaps halves back (16 DPP moves)
+    transpose32(w);
+#pragma unroll
+    for (int j = 0; j < vals; ++j) {
+        const uint32_t got = pair_swap(odd ? w[j] : w[vals + j]);  // the odd lane sends the low dwords of the even lane's values
+        r[j] = odd ? (static_cast<uint64_t>(got) << 32) | w[vals + j] : (static_cast<uint64_t>(w[j]) << 32) | got;
+    }
+}
+
+// row_shr:D inside the 16-lane DPP row with zero fill at the row start (a 64-bit value as two dwords)
+// (bound_ctrl with every row and bank enabled: the destination's old value is dead, so no register is zeroed for it first)
+template<int D>
+NDZIP_DEV uint64_t row_shift_up(uint64_t v) {
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(v)), 0x110 + D, 0xf, 0xf, true));
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(v >> 32)), 0x110 + D, 0xf, 0xf, true));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+NDZIP_DEV vec16 rotr1_pair(const vec16 &v) {
+    vec16 o;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint64_t x = rotr1(static_cast<uint64_t>(v.w[2 * j]) | (static_cast<uint64_t>(v.w[2 * j + 1]) << 32));
+        o.w[2 * j] = static_cast<uint32_t>(x);
+        o.w[2 * j + 1] = static_cast<uint32_t>(x >> 32);
+    }
+    return o;
+}
+
+// phases 2 + 3: residuals (already complemented) -> prefix sums along every axis -> rotr1 -> global.
+// `cube`: the region the run was staged into (consumed by now: a barrier inside orders that; 128-byte aligned), `smem`: the
+// workgroup's LDS (decode_layout).  Contains barriers: every work-item of the workgroup calls it; `active` guards the stores only.
+template<int Dims, bool Aligned>
+NDZIP_DEV void inverse_transform(uint64_t (&r)[vals], uint64_t *__restrict__ out, const grid_geom &gg, uint64_t origin, bool active,
+        char *cube, char *smem, int t) {
+    using W = uint64_t;
+    using V = value_layout;
+    using D = decode_layout<Dims>;
+    const int lane = t & 63, wave = wave_uniform(t >> 6);
+    const uint32_t region = lds_address(cube);
+
+    // ---- phase 2: prefix sums that stay inside the work-item / wavefront ----------------------------------
+#pragma unroll
+    for (int j = 1; j < vals; ++j) r[j] += r[j - 1];  // x (1D: the work-item's 16 consecutive values)
+    if constexpr (Dims == 1) {
+        W *carries = reinterpret_cast<W *>(smem + D::carries_offset);
+        const W incl = wave_inclusive_scan_w<W>(r[vals - 1], lane);
+        if (lane == 63) carries[wave] = incl;
+        __syncthreads();
+        W carry = incl - r[vals - 1];
+#pragma unroll
+        for (int w = 0; w < threads / 64 - 1; ++w) {
+            if (w < wave) carry += carries[w];
+        }
+#pragma unroll
+        for (int j = 0; j < vals; ++j) r[j] += carry;
+    } else if constexpr (Dims == 2) {
+        // work-item = quarter row (y = t / 4, quarter = t % 4): exclusive scan of the quarters' totals over the quad
+        const int qx = t & 3;
+        const uint32_t keep1 = static_cast<uint32_t>(opaque_vgpr(qx >= 1 ? -1 : 0)), keep2 = static_cast<uint32_t>(opaque_vgpr(qx >= 2 ? -1 : 0));
+        W incl = r[vals - 1];
+        incl += group8_shift_up<1>(incl, keep1);
+        incl += group8_shift_up<2>(incl, keep2);
+        const W left = incl - r[vals - 1];
+#pragma unroll
+        for (int j = 0; j < vals; ++j) r[j] += left;
+    } else {
+        // work-item = row (z, y) = (t / 16, t % 16): the 16 rows of a z-plane are the 16 lanes of a DPP row -- y is a plain row
+        // scan, no masks (lanes shifted in from outside the row read as 0)
+#pragma unroll
+        for (int j = 0; j < vals; ++j) r[j] += row_shift_up<1>(r[j]);
+#pragma unroll
+        for (int j = 0; j < vals; ++j) r[j] += row_shift_up<2>(r[j]);
+#pragma unroll
+        for (int j = 0; j < vals; ++j) r[j] += row_shift_up<4>(r[j]);
+#pragma unroll
+        for (int j = 0; j < vals; ++j) r[j] += row_shift_up<8>(r[j]);
+    }
+
+    __syncthreads();  // every work-item has consumed the encoded run: overwrite `cube` with values
+    {
+        const uint32_t row = V::row_base(region, static_cast<uint32_t>(t));  // work-item t holds row t
+#pragma unroll
+        for (int i = 0; i < vals / 2; ++i) {
+            vec16 v;
+            v.w[0] = static_cast<uint32_t>(r[2 * i]);
+            v.w[1] = static_cast<uint32_t>(r[2 * i] >> 32);
+            v.w[2] = static_cast<uint32_t>(r[2 * i + 1]);
+            v.w[3] = static_cast<uint32_t>(r[2 * i + 1] >> 32);
+            lds_write16(lds_pointer(row ^ (16u * static_cast<uint32_t>(i))), v);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: remaining axis sums in the store layout, rotr1, coalesced global store ---------------------
+    if constexpr (Dims == 1) {
+        constexpr int NV = hc_size / 2 / threads;  // 8 vectors of two values per work-item
+        // vector i of work-item t = values (256 i + t) * 2 = slot t % 8 of row 32 i + t / 8: one address, immediate offsets
+        const uint32_t src = V::row_base(region, static_cast<uint32_t>(t) >> 3) ^ (16u * (static_cast<uint32_t>(t) & 7u));
+        vec16 all[NV];  // (every read issued before the first store: one LDS round trip instead of NV)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) all[i] = lds_read16(lds_pointer(src) + i * (threads / 8) * 128);
+        if (active) {
+            // global address = (wave-uniform: the hypercube's origin + i x 4 KiB, scalar arithmetic) + (one 32-bit per-lane offset)
+            char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin));
+            const uint32_t lane_bytes = lane_offset_here(static_cast<uint32_t>(t) * 16u);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                global_store16<Aligned>(dst + lane_bytes, rotr1_pair(all[i]));
+                dst = scalar_pointer(dst + threads * 16);
+            }
+        }
+    } else if constexpr (Dims == 2) {
+        // work-item = column x of one QUARTER of the rows (wavefront k: rows 16 k .. 16 k + 15): column sums of the quarter in
+        // registers, the quarters' totals exchanged through LDS -- every wavefront reads 16 rows and stores 16 (the 128-work-item
+        // decoder lets its second wavefront re-read the first one's 32 rows instead: 64 dependent reads against 32)
+        W *columns = reinterpret_cast<W *>(smem + D::columns_offset);
+        const uint32_t x = static_cast<uint32_t>(lane);
+        const uint32_t y0 = static_cast<uint32_t>(wave) * 16u;
+        // value (y, x) = row 4 y + x / 16, slot (x / 2) % 8, half x % 2; the row's swizzle (4 y + x / 16) % 8 alternates with y % 2
+        const uint32_t even = (V::row_base(region, 4 * y0 + (x >> 4)) ^ (16u * ((x >> 1) & 7u))) + 8u * (x & 1u);
+        const uint32_t odd = even ^ 64u;
+        W v[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const W *>(lds_pointer((j & 1u) ? odd : even) + j * 512);
+#pragma unroll
+        for (int j = 1; j < 16; ++j) v[j] += v[j - 1];
+        if (wave < threads / 64 - 1) columns[wave * 64 + lane] = v[15];
+        __syncthreads();
+        W above = 0;
+#pragma unroll
+        for (int k = 0; k < threads / 64 - 1; ++k) {
+            if (k < wave) above += columns[k * 64 + lane];
+        }
+        if (active) {
+            // (uniform: the hypercube's row y0, a running scalar pointer; per lane: the column)
+            char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin + static_cast<uint64_t>(y0) * gg.stride[0]));
+            const uint64_t row_step = gg.stride[0] * sizeof(W);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                *reinterpret_cast<W *>(dst + lane_offset_here(x * static_cast<uint32_t>(sizeof(W)))) = rotr1(v[j] + above);
+                dst = scalar_pointer(dst + row_step);
+            }
+        }
+    } else {
+        // work-item = (y, x) for all 16 z: every wavefront reads 16 x 8 bytes per lane and stores them (four rows of 128 bytes
+        // = four whole cache lines per store instruction when the rows are aligned); value (z, y, x) = row 16 z + y, slot x / 2
+        const uint32_t y = static_cast<uint32_t>(t) >> 4, x = static_cast<uint32_t>(t) & 15u;
+        const uint32_t src = (V::row_base(region, y) ^ (16u * (x >> 1))) + 8u * (x & 1u);
+        W v[16];  // (all reads first: see inverse_transform_hypercube)
+#pragma unroll
+        for (uint32_t z = 0; z < 16; ++z) v[z] = *reinterpret_cast<const W *>(lds_pointer(src) + z * 2048);
+        if (active) {
+            // global address = (wave-uniform: hypercube origin + z planes, a running scalar pointer) + (32-bit per-lane byte offset
+            // inside a plane: row y, value x)
+            const uint32_t lane_bytes = (y * static_cast<uint32_t>(gg.stride[1]) + x) * static_cast<uint32_t>(sizeof(W));
+            const uint64_t plane_step = gg.stride[0] * sizeof(W);
+            char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin));
+            W acc = 0;
+#pragma unroll
+            for (uint32_t z = 0; z < 16; ++z) {
+                acc += v[z];
+                *reinterpret_cast<W *>(dst + lane_offset_here(lane_bytes)) = rotr1(acc);
+                dst = scalar_pointer(dst + plane_step);
+            }
+        }
+    }
+}
+
 }  // namespace wide
 }  // namespace ndzip_hip

@@ -48,6 +48,7 @@ struct decompress_args {
     bool aligned;
     uint32_t body_words;      // words of `body` the caller vouches for (hypercube runs + border); 0xffffffff = unknown
     int num_xcds;             // accelerator complexes (separate L2s) workgroups are dealt to round-robin: hipDeviceAttributeNumberOfXccs
+    int f64_work_items;       // work-items per 64-bit hypercube: 0 / 256 = decompress_kernel_wide (default), 128 = decompress_kernel
 };
 
 // hypercubes per compress / decompress workgroup for (T, dims)
@@ -73,6 +74,8 @@ enum debug_stage : int {
     debug_transpose32_generic = 5,
     debug_wave_scan = 6,          // in: n uint32 (n a multiple of 64)   -> out: per wavefront of 64, the inclusive prefix sums;
                                   //                                         out[n + w] = the wave sum of wavefront w
+    debug_decode_residuals_wide = 8,  // stage 2 through the 256-work-item f64 decoder (wide::decode_residuals); f64 only
+    debug_inverse_transform_wide = 9, // stage 3 through wide::inverse_transform; f64 only
     debug_lookback_scan = 7,      // in: n uint32 tile lengths           -> out: their n exclusive prefix sums, out[n] = the total,
                                   //     out[n + 1] = the error word; `hc` = workgroups of the persistent grid (0: as many as the
                                   //     production launch would use).  The production ticket / publish / look-back / release

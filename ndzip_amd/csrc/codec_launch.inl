@@ -792,6 +792,79 @@ decompress_kernel(const uint32_t *__restrict__ header, const uint32_t *__restric
             mis * static_cast<uint32_t>(sizeof(W)), xchg, t);
 }
 
+// ---- f64 with 256 work-items per hypercube (codec_kernels_wide.hpp: wide::decode_residuals / wide::inverse_transform) --------
+// Same header lookup, bounds and run staging as decompress_kernel; one hypercube per workgroup.  4 workgroups per CU by LDS
+// (35-36 KB each) = 16 wavefronts = 4 per SIMD, which the registers are held to (the 128-work-item kernel: 8 wavefronts per CU).
+template<int Dims>
+struct wide_decode_cfg {
+    static constexpr int threads = wide::threads;
+    static constexpr uint32_t smem_bytes = wide::decode_layout<Dims>::smem_bytes;
+    static constexpr int min_waves_per_simd = 4;
+};
+
+template<int Dims, bool Aligned>
+__global__ void __launch_bounds__((wide_decode_cfg<Dims>::threads), (wide_decode_cfg<Dims>::min_waves_per_simd))
+decompress_kernel_wide(const uint32_t *__restrict__ header, const uint32_t *__restrict__ header_base_ptr, const uint64_t *__restrict__ body,
+        uint64_t *__restrict__ out, const grid_geom gg, uint32_t *err, const uint32_t body_words, const uint32_t num_xcds) {
+    using W = uint64_t;
+    using P = profile<double, Dims>;
+    using D = wide::decode_layout<Dims>;
+    constexpr int threads = wide::threads;
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    const int t = static_cast<int>(threadIdx.x);
+    char *cube = smem;
+    uint32_t *totals = reinterpret_cast<uint32_t *>(smem + D::totals_offset);
+
+    // (tile order: see decompress_kernel -- aligned f64 rows are whole cache lines and keep the plain order)
+    constexpr bool xcd_ranges = !Aligned;
+    const uint32_t ntiles = gg.nhc;
+    const uint32_t per_xcd = (ntiles + num_xcds - 1) / num_xcds;
+    const uint32_t hc = xcd_ranges ? (blockIdx.x % num_xcds) * per_xcd + blockIdx.x / num_xcds : blockIdx.x;
+    const bool active = hc < gg.nhc;  // (grid rounded up to a multiple of num_xcds: surplus blocks idle)
+    uint32_t begin = 0, len = 0;
+    if (active) {
+        // header entries are trusted only as far as the format allows: see decompress_kernel
+        const uint32_t header_base = header_base_ptr ? *header_base_ptr : 0u;
+        begin = (hc ? header[hc - 1] : header_base) - header_base;  // stream<Profile>::hypercube, common.hh:350-358
+        len = header[hc] - header_base - begin;
+        const uint64_t lo = static_cast<uint64_t>(hc) * P::head_words, hi = static_cast<uint64_t>(hc) * P::max_hc_words;
+        if (len < static_cast<uint32_t>(P::head_words) || len > static_cast<uint32_t>(P::max_hc_words) || begin < lo || begin > hi
+                || static_cast<uint64_t>(begin) + len > body_words) {
+            if (t == 0) atomicOr(err, 2u);  // corrupt header
+            len = 0;
+        }
+    }
+    constexpr uint32_t wpv = 16 / sizeof(W);
+    constexpr int max_vec = (P::max_hc_words + wpv - 1 + wpv - 1) / wpv;  // run + worst misalignment
+    constexpr int vec_per_thread = (max_vec + threads - 1) / threads;      // 9
+    static_assert(static_cast<uint32_t>(max_vec) * 16u + 128u <= D::region_bytes, "run, and the plane word read behind it, inside the region");
+    uint32_t mis = 0;
+    if (len == 0) {
+        // padding workgroup or corrupt entry: decode an all-zero hypercube so every LDS index stays in range
+        if (t < P::head_words) *run_layout<W>::ptr(reinterpret_cast<W *>(cube) + t) = 0;
+    } else {
+        const W *src = body + begin;
+        mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(src) / sizeof(W)) % wpv);
+        const vec16 *src16 = reinterpret_cast<const vec16 *>(src - mis);
+        const uint32_t nvec = (len + mis + wpv - 1) / wpv;
+        vec16 v[vec_per_thread];  // (all loads of a work-item are issued before the first one is consumed)
+#pragma unroll
+        for (int i = 0; i < vec_per_thread; ++i) {
+            const uint32_t j = static_cast<uint32_t>(i * threads + t);
+            if (j < nvec) v[i] = global_load16_block(reinterpret_cast<const char *>(scalar_pointer(src16)) + lane_offset_here(16u * j));
+        }
+#pragma unroll
+        for (int i = 0; i < vec_per_thread; ++i) {
+            const uint32_t j = static_cast<uint32_t>(i * threads + t);
+            if (j < nvec) lds_write16(run_layout<W>::ptr(cube + 16 * j), v[i]);
+        }
+    }
+    __syncthreads();
+    W r[wide::vals];
+    wide::decode_residuals(cube, mis * static_cast<uint32_t>(sizeof(W)), totals, t, r);
+    wide::inverse_transform<Dims, Aligned>(r, out, gg, active ? hc_origin<Dims>(gg, hc) : 0, active, cube, smem, t);
+}
+
 // ---- stage kernels for the parity tests: exactly one hypercube, through the SAME device functions the production kernels
 // call (mirror of the reference's stage tests, src/test/codec_profile_test.inl:514-549, :552-729, :735-801, :889-947) --------
 
@@ -899,6 +972,21 @@ debug_stage_wide_kernel(int stage, const grid_geom gg, uint32_t hc, const uint64
             out[w] = *run_layout<W>::ptr(reinterpret_cast<const W *>(cube) + w);
         }
         if (t == 0) *out_len = total;
+    } else if (stage == debug_decode_residuals_wide) {
+        // (the decode stages use decode_layout: the run / the values in [0, cube_bytes), the exchange words behind them -- the
+        // launcher sizes the LDS for both layouts)
+        using P = profile<double, Dims>;
+        for (uint32_t w = t; w < P::max_hc_words; w += wide::threads) {
+            *run_layout<W>::ptr(reinterpret_cast<W *>(cube) + w) = in[w];
+        }
+        __syncthreads();
+        wide::decode_residuals(cube, 0, reinterpret_cast<uint32_t *>(smem + wide::decode_layout<Dims>::totals_offset), t, r);
+        // (the production path undoes complement_negative in the plane domain; the stage's contract is the residuals as encoded)
+        for (int j = 0; j < wide::vals; ++j) out[t * wide::vals + j] = complement_negative(r[j]);
+    } else if (stage == debug_inverse_transform_wide) {
+        for (int j = 0; j < wide::vals; ++j) r[j] = complement_negative(in[t * wide::vals + j]);
+        __syncthreads();
+        wide::inverse_transform<Dims, Aligned>(r, out, gg, hc_origin<Dims>(gg, hc), true, cube, smem, t);
     }
 }
 
@@ -1063,6 +1151,16 @@ hipError_t launch_decompress_profile(const decompress_args &a) {
     const uint32_t ntiles = (a.gg.nhc + C::K - 1) / C::K;
     if (ntiles == 0) return hipSuccess;
     const uint32_t xcds = a.num_xcds > 0 ? static_cast<uint32_t>(a.num_xcds) : 1u;
+    if constexpr (sizeof(T) == 8) {
+        // f64: 256 work-items per hypercube unless the caller asked for the 128-work-item mapping (an A/B switch on the handle)
+        if (a.f64_work_items != 128) {
+            using WC = wide_decode_cfg<Dims>;
+            const uint32_t grid = (a.gg.nhc + xcds - 1) / xcds * xcds;
+            hipLaunchKernelGGL((decompress_kernel_wide<Dims, Aligned>), dim3(grid), dim3(WC::threads), WC::smem_bytes, a.stream, a.header,
+                    a.header_base, static_cast<const W *>(a.body), static_cast<W *>(a.out), a.gg, a.err, a.body_words, xcds);
+            return hipGetLastError();
+        }
+    }
     const uint32_t grid = (ntiles + xcds - 1) / xcds * xcds;  // see the kernel: tiles are dealt to XCDs in contiguous ranges
     hipLaunchKernelGGL((decompress_kernel<T, Dims, Aligned>), dim3(grid), dim3(C::threads), C::smem_bytes, a.stream,
             a.header, a.header_base, static_cast<const W *>(a.body), static_cast<W *>(a.out), a.gg, a.err, a.body_words, xcds);
@@ -1074,9 +1172,11 @@ hipError_t launch_debug_profile(int stage, const grid_geom &gg, uint32_t hc, con
         hipStream_t stream) {
     using W = typename word_of<T>::type;
     if constexpr (sizeof(W) == 8) {
-        if (stage == debug_forward_transform || stage == debug_encode_residuals) {
+        if (stage == debug_forward_transform || stage == debug_encode_residuals || stage == debug_decode_residuals_wide
+                || stage == debug_inverse_transform_wide) {
             using L = wide::layout<W>;
-            const uint32_t smem = L::cube_bytes + L::zero_bytes + 64;
+            constexpr uint32_t enc = L::cube_bytes + L::zero_bytes + 64, dec = wide::decode_layout<Dims>::smem_bytes;
+            const uint32_t smem = enc > dec ? enc : dec;
             hipLaunchKernelGGL((debug_stage_wide_kernel<Dims, Aligned>), dim3(1), dim3(wide::threads), smem, stream, stage, gg, hc,
                     static_cast<const W *>(in), static_cast<W *>(out), out_len);
             return hipGetLastError();

@@ -61,6 +61,7 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_decompressor_decompress_bounded",
     "ndzip_hip_decompressor_decompress_split",
     "ndzip_hip_decompressor_decompress_split_bounded",
+    "ndzip_hip_decompressor_set_f64_work_items",
     "ndzip_hip_decompressor_check",
     "ndzip_hip_decompressor_destroy",
     "ndzip_hip_offload_compress",
@@ -145,6 +146,7 @@ def _bind(L, strict: bool = True):
     L.ndzip_hip_compressor_offset_header_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ndzip_hip_compressor_check.argtypes = [C.c_void_p]
     L.ndzip_hip_compressor_set_max_workgroups_per_cu.argtypes = [C.c_void_p, C.c_int]
+    L.ndzip_hip_decompressor_set_f64_work_items.argtypes = [C.c_void_p, C.c_int]
     L.ndzip_hip_compressor_destroy.argtypes = [C.c_void_p]
     L.ndzip_hip_decompressor_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.ndzip_hip_decompressor_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _U32P]
@@ -332,6 +334,10 @@ class HipDecompressor:
             _check(lib().ndzip_hip_decompressor_decompress_split_bounded(self._h, _ptr(device_header), _ptr(device_header_base),
                                                                          _ptr(device_body), int(body_words), _ptr(out_device_data),
                                                                          len(extent), _ext(extent)))
+
+    def set_f64_work_items(self, n: int) -> None:
+        """A/B switch: work-items per 64-bit hypercube -- 0 (default = 256), 128 or 256; same bits either way."""
+        _check(lib().ndzip_hip_decompressor_set_f64_work_items(self._h, int(n)))
 
     def check(self) -> None:
         _check(lib().ndzip_hip_decompressor_check(self._h))

@@ -101,10 +101,14 @@ def test_compress_and_decompress_kernels_do_not_spill():
         build.build(force=True)
         res = build.kernel_resources()
     hot = {k: v for k, v in res.items() if "compress_kernel" in k}  # compress_kernel, compress_kernel_db, decompress_kernel
-    assert len(hot) == 25, sorted(res)  # f32 db (7: 6 + the paired 3D variant) + f64 wide (6) + decompress (12)
+    assert len(hot) == 31, sorted(res)  # f32 db (7: 6 + the paired 3D variant) + f64 wide (6) + decompress (12) + f64 wide decompress (6)
     for name, r in hot.items():
         assert r["scratch"] == 0, f"{name} spills {r['scratch']} bytes per lane"
     # every compress kernel runs 4 workgroups per CU: 128 VGPRs at most, still no scratch (round 2: 143-168 VGPRs, 3 per CU)
+    # the 256-work-item f64 decoder: 4 workgroups of 4 wavefronts per CU by its LDS (35-36 KB), so 4 wavefronts per SIMD must fit
+    # the registers with room to spare (the 128-work-item one: 146 VGPRs, 3 by registers and 2 by LDS)
+    wide_dec = {k: v for k, v in hot.items() if "decompress_kernel_wide" in k}
+    assert len(wide_dec) == 6 and all(r["occupancy"] >= 4 and r["vgprs"] <= 96 for r in wide_dec.values()), wide_dec
     comp = {k: v for k, v in hot.items() if "decompress" not in k}
     assert len(comp) == 13 and all(r["occupancy"] == 4 and r["vgprs"] <= 128 for r in comp.values()), comp
     # SGPR spills are VGPR-lane traffic (v_readlane + hazard nops) inside the persistent loop: 45-49 before round 3

@@ -10,6 +10,7 @@ for f64, unaligned extents (scalar load path) and the host-pointer offloader."""
 import numpy as np
 import pytest
 
+from ndzip_amd.synth import synth_numpy
 from oracle import oracle
 from tests.util import (PROFILES, SIDE, device_compress, device_decompress, profile_id, random_bits, random_unit_floats,
                         same_bits, word_dtype)
@@ -113,6 +114,35 @@ def test_dense_and_sparse_chunks_mixed(hiplib, cuda_device, profile):
     stream = _check_stream(data)
     assert same_bits(device_decompress(stream, dtype, shape), data)
     assert same_bits(device_decompress(oracle.compress(data), dtype, shape), data)
+
+
+@pytest.mark.parametrize("dims", [1, 2, 3])
+@pytest.mark.parametrize("work_items", [128, 256])
+def test_f64_decoder_mappings_agree(hiplib, cuda_device, dims, work_items):
+    """ndzip_hip_decompressor_set_f64_work_items: the 64-bit decoder with 256 work-items per hypercube (decompress_kernel_wide, the
+    default: every other float64 test in this suite runs it) and with 128 (decompress_kernel) decode the oracle's streams to the
+    same bits -- incompressible hypercubes (the wave-uniform dense path of the wide decoder: every chunk of a wavefront keeps all
+    64 planes), smooth data, zeros, the mixed dense / sparse pattern, unaligned rows with a border."""
+    import ndzip_amd
+
+    dtype = np.float64
+    side = SIDE[dims]
+    shapes = {1: [(side * 5,), (side * 3 + 17,)], 2: [(side * 2, side * 3), (side * 2 + 3, side + 9)],
+              3: [(side * 2, side, side * 2), (side + 1, side * 2 + 2, side + 3)]}[dims]
+    for i, shape in enumerate(shapes):
+        rng = np.random.default_rng(100 * dims + i)
+        mixed = random_bits(shape, dtype, 70 + i).view(np.uint64).reshape(-1).copy()
+        for _ in range(max(1, mixed.size // 500)):
+            a = int(rng.integers(0, max(1, mixed.size - 300)))
+            mixed[a:a + int(rng.integers(1, 300))] &= np.uint64(0xFFFFFFFFFFFFFFFF >> int(rng.integers(1, 63)))
+        for data in (random_bits(shape, dtype, 60 + i), random_unit_floats(shape, dtype, 61 + i), np.zeros(shape, dtype),
+                     synth_numpy(shape, dtype, seed=62 + i, noise_mask=0xFFFF), mixed.view(dtype).reshape(shape)):
+            stream = oracle.compress(data)
+            assert same_bits(device_decompress(stream, dtype, shape, f64_work_items=work_items), data)
+    dec = ndzip_amd.make_hip_decompressor(dtype, dims)
+    with pytest.raises(ndzip_amd.NdzipHipError):
+        dec.set_f64_work_items(64)
+    dec.close()
 
 
 @pytest.mark.parametrize("profile", PROFILES, ids=profile_id)

@@ -17,6 +17,7 @@ from tests.util import PROFILES, SIDE, profile_id, random_bits, random_unit_floa
 pytestmark = pytest.mark.gpu
 
 FWD, ENC, DEC, INV, TR, TRG = 0, 1, 2, 3, 4, 5
+DEC_WIDE, INV_WIDE = 8, 9  # stages 2 / 3 through the 256-work-item decoder of the 64-bit profiles
 
 
 def _t(a, device):
@@ -129,9 +130,11 @@ def test_residual_encoding_matches_oracle(hiplib, cuda_device, profile, pattern)
     d_res = torch.zeros(4096, dtype=d_in.dtype, device=cuda_device)
     d_stream = torch.zeros(4096 + 4096 // bits, dtype=d_in.dtype, device=cuda_device)
     d_stream[: len(want)] = _t(want, cuda_device)
-    hip.debug_stage(DEC, dtype, dims, None, 0, d_stream, d_res)
-    torch.cuda.synchronize()
-    assert np.array_equal(_np(d_res, wdt), res)
+    for stage in ([DEC, DEC_WIDE] if bits == 64 else [DEC]):
+        d_res.zero_()
+        hip.debug_stage(stage, dtype, dims, None, 0, d_stream, d_res)
+        torch.cuda.synchronize()
+        assert np.array_equal(_np(d_res, wdt), res), stage
 
 
 @pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
@@ -149,13 +152,14 @@ def test_inverse_transform_matches_oracle(hiplib, cuda_device, profile, aligned)
     want_cube = oracle.inverse_transform(res, dims)
     n = int(np.prod(shape))
     for hc in sorted({0, nhc - 1}):
-        d_out = torch.zeros(n, dtype=torch.int32 if wdt == np.uint32 else torch.int64, device=cuda_device)
-        hip.debug_stage(INV, dtype, dims, shape, hc, _t(res, cuda_device), d_out)
-        torch.cuda.synchronize()
-        got = _np(d_out, wdt).reshape(shape)
-        assert np.array_equal(oracle.load_cube(got.view(dtype), hc), want_cube), hc
-        # nothing outside the hypercube was touched
-        assert np.count_nonzero(got) <= 4096
+        for stage in ([INV, INV_WIDE] if wdt == np.uint64 else [INV]):
+            d_out = torch.zeros(n, dtype=torch.int32 if wdt == np.uint32 else torch.int64, device=cuda_device)
+            hip.debug_stage(stage, dtype, dims, shape, hc, _t(res, cuda_device), d_out)
+            torch.cuda.synchronize()
+            got = _np(d_out, wdt).reshape(shape)
+            assert np.array_equal(oracle.load_cube(got.view(dtype), hc), want_cube), (hc, stage)
+            # nothing outside the hypercube was touched
+            assert np.count_nonzero(got) <= 4096
 
 
 @pytest.mark.parametrize("profile", PROFILES, ids=profile_id)

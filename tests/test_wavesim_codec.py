@@ -287,6 +287,8 @@ def test_result_does_not_depend_on_the_order_work_items_run_in(profile, schedule
     got = sim.compress(data, cus=3, blocks_per_cu=2, schedule=schedule)
     assert len(got) == len(want) and np.array_equal(got, want)
     assert same_bits(sim.decompress(want, dtype, shape, schedule=schedule), data)
+    if np.dtype(dtype).itemsize == 8:  # (the default above is the 256-work-item decoder; the 128-work-item one stays selectable)
+        assert same_bits(sim.decompress(want, dtype, shape, schedule=schedule, f64_work_items=128), data)
 
 
 @pytest.mark.parametrize("shape", [(32, 32, 48), (16, 48, 16), (48, 16, 80)])

@@ -69,7 +69,7 @@ def device_compress(data: np.ndarray, device=None):
     return out
 
 
-def device_decompress(stream: np.ndarray, dtype, extent, device=None):
+def device_decompress(stream: np.ndarray, dtype, extent, device=None, f64_work_items: int = 0):
     import torch
 
     import ndzip_amd
@@ -84,6 +84,8 @@ def device_decompress(stream: np.ndarray, dtype, extent, device=None):
         d_stream = torch.zeros(1, dtype=wdt, device=device)
     d_out = torch.zeros(max(1, n), dtype=wdt, device=device)
     dec = ndzip_amd.make_hip_decompressor(dtype, len(extent), torch.cuda.current_stream().cuda_stream)
+    if f64_work_items:
+        dec.set_f64_work_items(f64_work_items)  # (A/B switch of the 64-bit decoder: 128 / 256 work-items per hypercube)
     dec.decompress(d_stream, d_out, extent)
     dec.check()
     out = d_out[:n].cpu().numpy().view(dtype).reshape(extent)

@@ -5,6 +5,7 @@
 Nothing under ndzip_amd/ imports or loads this; tests/test_wavesim_*.py do.  `python -m tests.wavesim.build`."""
 from __future__ import annotations
 
+import fcntl
 import os
 import shutil
 import subprocess
@@ -49,8 +50,22 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
     OUT = os.path.join(HERE, f"libndzip_hip_wavesim{'_' + variant if variant else ''}.so")
     BUILD = os.path.join(HERE, "_build", variant or "default")
     FLAGS = list(globals()["FLAGS"]) + [f"-D{d}" for d in defines] + list(extra_flags)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in _sources()):
+    def fresh():
+        return os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in _sources())
+
+    if not force and fresh():
         return OUT
+    # One builder per variant at a time, across processes (the ranks of a torch.distributed.run rehearsal and pytest-xdist workers
+    # all come here when a kernel source is newer than the library): the others wait for the lock and find the library fresh.
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    with open(os.path.join(HERE, "_build", f".lock_{variant or 'default'}"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():
+            return OUT
+        return _build_locked(OUT, BUILD, FLAGS, verbose, extra_flags, kernel_flags)
+
+
+def _build_locked(OUT, BUILD, FLAGS, verbose, extra_flags, kernel_flags) -> str:
     # mirror the product tree so that its relative includes resolve, with the one substituted header
     src = os.path.join(BUILD, "ndzip_amd", "csrc")
     shutil.rmtree(BUILD, ignore_errors=True)
@@ -76,10 +91,12 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
     jobs.append((os.path.join(HERE, "wavesim.cc"), os.path.join(BUILD, "wavesim.o")))
     with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(compile_one, jobs))
-    cmd = [CXX, "-shared", "-fPIC", "-pthread", *[f for f in extra_flags if f.startswith(("-fsanitize", "-shared-lib"))], "-o", OUT, *objs]
+    tmp = OUT + f".tmp{os.getpid()}"  # (linked next to the library, then renamed: a process that has the old one mapped keeps it)
+    cmd = [CXX, "-shared", "-fPIC", "-pthread", *[f for f in extra_flags if f.startswith(("-fsanitize", "-shared-lib"))], "-o", tmp, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"wavesim link failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, OUT)
     return OUT
 
 

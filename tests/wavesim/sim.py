@@ -72,13 +72,15 @@ def compress(data: np.ndarray, cus: int = 2, blocks_per_cu: int = 2, misalign_wo
     return out[misalign_words:misalign_words + n].copy()
 
 
-def decompress(stream: np.ndarray, dtype, extent, bounded: bool = False, schedule: str = "") -> np.ndarray:
+def decompress(stream: np.ndarray, dtype, extent, bounded: bool = False, schedule: str = "", f64_work_items: int = 0) -> np.ndarray:
     stream = np.ascontiguousarray(stream)
     out = np.zeros(extent, dtype=dtype)
     with active(schedule=schedule):
         dec = hip.make_hip_decompressor(dtype, len(extent))
         try:
             buf = stream if stream.size else np.zeros(1, dtype=_words(dtype))
+            if f64_work_items:
+                dec.set_f64_work_items(f64_work_items)
             dec.decompress(buf.ctypes.data, out.ctypes.data, extent, stream.size if bounded else None)
             dec.check()
         finally:

@@ -43,7 +43,7 @@ def symbolize(lib, offsets):
     return out
 
 
-def run(shape, dtype, data, mode):
+def run(shape, dtype, data, mode, f64_work_items=0):
     from ndzip_amd import hip, synth
     from tests.wavesim import sim
 
@@ -73,6 +73,8 @@ def run(shape, dtype, data, mode):
             results["compress"] = [json.loads(l) for l in open(f.name)]
         y = np.empty_like(x)
         dec = hip.make_hip_decompressor(x.dtype, x.ndim)
+        if f64_work_items:
+            dec.set_f64_work_items(f64_work_items)
         dec.decompress(out.ctypes.data, y.ctypes.data, x.shape)
         dec.check()
         assert np.array_equal(y.view(W), x.view(W))
@@ -120,9 +122,10 @@ def main():
     ap.add_argument("--data", default="synth", choices=["synth", "random", "zeros"])
     ap.add_argument("--mode", default="both", choices=["compress", "decompress", "both"])
     ap.add_argument("--top", type=int, default=25)
+    ap.add_argument("--f64-work-items", type=int, default=0, help="64-bit decoder: 0 (the library's default = 256), 128 or 256 work-items per hypercube")
     a = ap.parse_args()
     shape = tuple(int(s) for s in a.shape.split(","))
-    results, ratio = run(shape, a.dtype, a.data, a.mode)
+    results, ratio = run(shape, a.dtype, a.data, a.mode, a.f64_work_items)
     from ndzip_amd import hip
 
     nhc = hip.num_hypercubes(shape)
