@@ -23,7 +23,7 @@ header all-gather (ndzip_amd/sharded.py); bodies stay resident.
 ranks, divided by the wall time of the K timed steps (barrier + synchronize on both sides, max over ranks).
 
 Extra objects:
-  roofline      the dominant kernel of the step (compress_kernel_db<float,D> / compress_kernel_wide<u64,D>; decompress_kernel
+  roofline      the dominant kernel of the step (compress_kernel_db<float,D> / compress_kernel_wide<u64,D>; decompress_kernel / decompress_kernel_wide<D>
                 for decompress-only runs): algorithmic bytes (raw + stream) per launch over the HIP-event
                 duration of the launch on the stream it runs on; peak 8 TB/s (HBM3E spec).  The other kernel rides along.
   cpu_baseline  the GENUINE reference CPU codec (oracle/_ref, compiled from /root/reference; serial path -- its OpenMP path
@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--smooth", action="store_true", help="highly compressible bookend (two low-frequency octaves)")
     ap.add_argument("--data", type=str, default="synthetic", choices=["synthetic", "random", "zeros"])
     ap.add_argument("--workgroups-per-cu", type=int, default=0, help="cap the persistent compress grid (0 = default: 4 per CU); 3 = the round-2 grid, for an A/B of the occupancy")
+    ap.add_argument("--f64-work-items", type=int, default=0, choices=[0, 128, 256], help="64-bit decoder mapping: 0 = the library's default (256 work-items per hypercube, decompress_kernel_wide), 128 = decompress_kernel; for an A/B of the two")
     ap.add_argument("--overlap-exchange", action="store_true", help="N > 1: leave the offset / header exchange in flight behind the decompress launch (opt-in until it has run over RCCL on a multi-GPU node; default: compress -> exchange -> decompress, every collective waited for)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg")
@@ -417,6 +418,8 @@ def main(argv=None):
     codec = ShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and args.overlap_exchange)
     if args.workgroups_per_cu:
         codec.compressor.set_max_workgroups_per_cu(args.workgroups_per_cu)
+    if args.f64_work_items:
+        codec.decompressor.set_f64_work_items(args.f64_work_items)
     shard = codec.shard
 
     # ---- synthetic input, generated directly in HBM (identical bits on every machine) ------------------------------
@@ -505,7 +508,8 @@ def main(argv=None):
         algo_bytes_per_launch = (raw_total + stream_bytes_total) / world
         slabs = plan_shards(global_extent, world)
         kernel_c = f"compress_kernel_db<float,{dims}>" if wb == 4 else f"compress_kernel_wide<unsigned long,{dims}>"
-        kernel_d = f"decompress_kernel<{'float' if wb == 4 else 'double'},{dims}>"
+        kernel_d = (f"decompress_kernel<{'float' if wb == 4 else 'double'},{dims}>" if wb == 4 or args.f64_work_items == 128
+                    else f"decompress_kernel_wide<{dims}>")
 
         def leg(t):
             a = algo_bytes_per_launch / t / 1e9

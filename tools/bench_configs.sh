@@ -15,6 +15,14 @@ run --shape 512,512,512 --dtype float32 --data zeros
 run --shape 512,512,512 --dtype float32 --data random
 run --shape 510,511,509 --dtype float32
 run --config 4
+# A/B of the 64-bit decoder: the 128-work-item kernel (the lines above ran the default, 256 work-items per hypercube)
+echo "-- f64 decoder with 128 work-items per hypercube:"
+run --shape 8192,8192 --dtype float64 --f64-work-items 128
+run --shape 512,512,512 --dtype float64 --f64-work-items 128
+run --shape 67108864 --dtype float64 --f64-work-items 128
+run --shape 8192,8192 --dtype float64 --data random --f64-work-items 128
+echo "-- (default mapping, random bits 2D f64, for the line above:)"
+run --shape 8192,8192 --dtype float64 --data random
 python bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']

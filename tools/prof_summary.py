@@ -15,7 +15,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(compress_kernel_db|compress_kernel|decompress_kernel|border_kernel|debug_\w+|offset_header\w*|store_length\w*)<?([^>(]*)", name)
+    m = re.search(r"(decompress_kernel_wide|decompress_kernel|compress_kernel_wide|compress_kernel_db|compress_kernel|border_kernel|debug_\w+|offset_header\w*|store_length\w*)<?([^>(]*)", name)
     if m:
         return (m.group(1) + "<" + m.group(2) + ">").replace("ndzip_hip::", "")
     return name[:80]
