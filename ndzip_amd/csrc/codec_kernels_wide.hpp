@@ -502,9 +502,10 @@ NDZIP_DEV void inverse_transform(uint64_t (&r)[vals], uint64_t *__restrict__ out
             // (uniform: the hypercube's row y0, a running scalar pointer; per lane: the column)
             char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin + static_cast<uint64_t>(y0) * gg.stride[0]));
             const uint64_t row_step = gg.stride[0] * sizeof(W);
+            const uint32_t lane_bytes = lane_offset_here(x * static_cast<uint32_t>(sizeof(W)));  // (once: the stores share a basic block)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                *reinterpret_cast<W *>(dst + lane_offset_here(x * static_cast<uint32_t>(sizeof(W)))) = rotr1(v[j] + above);
+                *reinterpret_cast<W *>(dst + lane_bytes) = rotr1(v[j] + above);
                 dst = scalar_pointer(dst + row_step);
             }
         }
@@ -519,14 +520,14 @@ NDZIP_DEV void inverse_transform(uint64_t (&r)[vals], uint64_t *__restrict__ out
         if (active) {
             // global address = (wave-uniform: hypercube origin + z planes, a running scalar pointer) + (32-bit per-lane byte offset
             // inside a plane: row y, value x)
-            const uint32_t lane_bytes = (y * static_cast<uint32_t>(gg.stride[1]) + x) * static_cast<uint32_t>(sizeof(W));
+            const uint32_t lane_bytes = lane_offset_here((y * static_cast<uint32_t>(gg.stride[1]) + x) * static_cast<uint32_t>(sizeof(W)));
             const uint64_t plane_step = gg.stride[0] * sizeof(W);
             char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin));
             W acc = 0;
 #pragma unroll
             for (uint32_t z = 0; z < 16; ++z) {
                 acc += v[z];
-                *reinterpret_cast<W *>(dst + lane_offset_here(lane_bytes)) = rotr1(acc);
+                *reinterpret_cast<W *>(dst + lane_bytes) = rotr1(acc);  // (one offset register for the 16 stores: they share a basic block)
                 dst = scalar_pointer(dst + plane_step);
             }
         }

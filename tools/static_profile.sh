@@ -31,6 +31,11 @@ for k in "f32 decompress_kernelIfLi3ELb1E" "f32 decompress_kernelIfLi1ELb1E" "f6
     python "$root/tools/isa_cost.py" "$tmp/${v}_$1.s" "$2" | sed -n '2p'
   done
 done
+echo "# f64 decoder with 256 work-items per hypercube (head only; wave-instructions per hypercube = 4 x these, the 128-work-item kernel: 2 x its)"
+for k in decompress_kernel_wideILi1ELb1E decompress_kernel_wideILi2ELb1E decompress_kernel_wideILi3ELb1E; do
+  echo "## head  $k"
+  python "$root/tools/isa_cost.py" "$tmp/head_f64.s" "$k" | sed -n '2p'
+done
 echo "# hipcc -Rpass-analysis=kernel-resource-usage (head): VGPRs / scratch / occupancy of the codec kernels"
 for t in f32 f64; do
   python - "$tmp/head_$t.remarks" <<'PY'
