@@ -243,19 +243,8 @@ NDZIP_HIP_API int ndzip_hip_chunked_compress(int dtype, int dims, const uint64_t
 NDZIP_HIP_API int ndzip_hip_chunked_decompress(int dtype, int dims, const uint64_t *extent, uint64_t max_elements, const void *streams,
         uint64_t total_words, void *data, uint64_t *words_consumed, uint64_t *kernel_ns);
 
-/* ---- stage entry points (parity tests; mirror the reference's stage-level tests
- *      src/test/codec_profile_test.inl:514-549, :552-729, :735-801, :889-947) ----------------------------------- */
-
-/* stage: 0 forward transform of hypercube `hc` of the device array `d_in` -> 4096 residual words in `d_out`
- *        1 encode 4096 residual words -> encoded run in `d_out` (4096 + 4096/B words capacity), *d_out_len words
- *        2 decode an encoded run -> 4096 residual words
- *        3 inverse transform of 4096 residual words -> hypercube `hc` of the device array `d_out`
- *        4 / 5 32x32 bit transposes of `n` blocks of 32 uint32 (v_perm network / shift-mask network)
- *        8 / 9 stages 2 / 3 through the 256-work-item decoder of the 64-bit profiles (dtype NDZIP_HIP_F64 only)
- *        6 the wave64 scan and sum (DPP): `n` uint32 (a multiple of 64) -> per wavefront the inclusive prefix sums, then
- *          n / 64 wave totals behind them (`d_out` holds n + n / 64 words) */
-NDZIP_HIP_API int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in,
-        void *d_out, uint32_t *d_out_len, uint32_t n, void *hip_stream);
+/* The stage entry points of the parity tests (one hypercube through the kernels' device functions) are not part of this
+ * interface: include/ndzip_hip_stages.h, libndzip_hip_stages.so. */
 
 #ifdef __cplusplus
 }

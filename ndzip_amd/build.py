@@ -1,4 +1,6 @@
-"""Build the gfx950 HIP library in-tree: ndzip_amd/libndzip_hip.so.
+"""Build the gfx950 HIP libraries in-tree: ndzip_amd/libndzip_hip.so (the product: include/ndzip_hip.h) and
+ndzip_amd/libndzip_hip_stages.so (parity-test hooks only: include/ndzip_hip_stages.h -- the single-hypercube stage kernels, which
+the product library does not contain).
 
 `python -m ndzip_amd.build` (or `__graft_entry__.build()`) cross-compiles without a GPU.  The three
 translation units are compiled in parallel; objects go to ndzip_amd/csrc/_build/ (git-ignored).
@@ -13,12 +15,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libndzip_hip.so")
+STAGES_OUT = os.path.join(HERE, "libndzip_hip_stages.so")
 OBJDIR = os.path.join(CSRC, "_build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 SOURCES = ["kernels_f32.hip", "kernels_f64.hip", "capi.hip"]
+STAGE_SOURCES = ["stages_f32.hip", "stages_f64.hip", "stages_capi.hip"]  # -> libndzip_hip_stages.so (test hooks)
 # every header a translation unit can see: a stale object for the newest kernel is the worst kind of benchmark bug
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inl"))) + ["../../include/ndzip_hip.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inl"))) + ["../../include/ndzip_hip.h", "../../include/ndzip_hip_stages.h"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # No atomic optimizer: it rewrites the single-lane ticket atomicAdd into mbcnt + atomic + readfirstlane and waits for the
 # result on the spot, which puts the atomic's round trip back on the path the kernel takes care to hide it behind the copy-out.
@@ -37,11 +41,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     jobs = []
-    objs = []
-    for src in SOURCES:
+    objs, stage_objs = [], []
+    for src in SOURCES + STAGE_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        objs.append(o)
+        (objs if src in SOURCES else stage_objs).append(o)
         if force or _stale(o, [s] + headers):
             jobs.append([HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o])
 
@@ -56,10 +60,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 f.write(r.stderr)
         return r
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    with ThreadPoolExecutor(max_workers=len(SOURCES) + len(STAGE_SOURCES)) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs])
+    if force or jobs or _stale(STAGES_OUT, stage_objs):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", STAGES_OUT, *stage_objs])
     build_cli(force=force, verbose=verbose)
     return OUT
 

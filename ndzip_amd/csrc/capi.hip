@@ -14,30 +14,10 @@
 #include <string>
 
 #define NDZIP_HIP_BUILD 1
-#include "../../include/ndzip_hip.h"
-#include "codec_common.hpp"
+#include "capi_common.hpp"
 #include "codec_launch.hpp"
 
-using namespace ndzip_hip;
-
 namespace {
-
-thread_local std::string g_last_error;
-
-int fail(int status, const std::string &msg) {
-    g_last_error = msg;
-    return status;
-}
-
-int fail_hip(hipError_t e, const char *what) {
-    return fail(NDZIP_HIP_ERR_RUNTIME, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define HIP_TRY(expr)                                          \
-    do {                                                       \
-        hipError_t e_ = (expr);                                \
-        if (e_ != hipSuccess) return fail_hip(e_, #expr);      \
-    } while (0)
 
 // NDZIP_VERBOSE (any non-empty value), the reference's only tracing switch (src/ndzip/common.hh:630-633): the device-pointer
 // entry points report the hypercube count when they enqueue (cuda_codec.inl:565-567; nothing is timed there -- they never
@@ -51,49 +31,10 @@ bool verbose() {
     return on;
 }
 
-bool valid_dtype(int dtype) { return dtype == NDZIP_HIP_F32 || dtype == NDZIP_HIP_F64; }
-bool valid_dims(int dims) { return dims >= 1 && dims <= 3; }
-size_t word_bytes(int dtype) { return dtype == NDZIP_HIP_F32 ? 4 : 8; }
-uint32_t header_words_for(int dtype, uint32_t nhc) { return dtype == NDZIP_HIP_F32 ? nhc : (nhc + 1) / 2; }
-
-// The calling thread's current device: its ordinal, compute units and accelerator complexes (XCDs, each with its own L2;
-// 8 on an MI355X in SPX mode -- asked of the runtime, not assumed: a partitioned device reports fewer).
-int ensure_device(int *num_cus, int *device = nullptr, int *num_xcds = nullptr) {
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0) {
-        (void) hipGetLastError();
-        return fail(NDZIP_HIP_ERR_NO_DEVICE, "no HIP device visible: the ndzip HIP back-end has no CPU fallback");
-    }
-    int dev = 0;
-    if (num_cus || device || num_xcds) HIP_TRY(hipGetDevice(&dev));
-    if (device) *device = dev;
-    if (num_cus) HIP_TRY(hipDeviceGetAttribute(num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (num_xcds) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || n < 1) {
-            (void) hipGetLastError();
-            n = 1;  // unknown: tiles in plain order (only locality depends on it)
-        }
-        *num_xcds = n;
-    }
-    return NDZIP_HIP_OK;
-}
-
 // compressed_length_bound (common.cc:31-55), in 64 bits
 uint64_t length_bound(int dtype, const grid_geom &gg) {
     const uint64_t B = dtype == NDZIP_HIP_F32 ? 32 : 64;
     return header_words_for(dtype, gg.nhc) + static_cast<uint64_t>(gg.nhc) * (hc_size / B * (B + 1)) + border_count(gg);
-}
-
-// 16-byte vector path is legal when the base pointer and every hypercube-row start are 16-byte aligned
-bool is_aligned(int dtype, const grid_geom &gg, const void *data) {
-    const uint64_t ve = 16 / word_bytes(dtype);
-    if (reinterpret_cast<uintptr_t>(data) % 16 != 0) return false;
-    for (uint32_t d = 0; d + 1 < gg.dims; ++d) {
-        if (gg.stride[d] % ve != 0) return false;
-    }
-    return true;
 }
 
 int check_limits(int dtype, const grid_geom &gg) {
@@ -1055,27 +996,6 @@ int ndzip_hip_chunked_decompress(int dtype, int dims, const uint64_t *extent, ui
     if (status) return status;
     if (words_consumed) *words_consumed = consumed;
     if (kernel_ns) *kernel_ns = ns_total;
-    return NDZIP_HIP_OK;
-}
-
-int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in, void *d_out,
-        uint32_t *d_out_len, uint32_t n, void *hip_stream) {
-    if (!valid_dtype(dtype) || !valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");
-    if (int s = ensure_device(nullptr)) return s;
-    uint32_t one[3] = {side_for_dims(dims), side_for_dims(dims), side_for_dims(dims)};
-    const grid_geom gg = make_geom(dims, extent ? extent : one);
-    const bool inverse = stage == debug_inverse_transform || stage == debug_inverse_transform_wide;
-    const void *array = stage == debug_forward_transform ? d_in : inverse ? d_out : nullptr;
-    const bool aligned = array ? is_aligned(dtype, gg, array) : true;
-    if ((stage == debug_decode_residuals_wide || stage == debug_inverse_transform_wide) && dtype != NDZIP_HIP_F64) {
-        return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "stages 8 / 9 are the 256-work-item decoder of 64-bit profiles");
-    }
-    if ((stage == debug_forward_transform || inverse) && hc >= gg.nhc) {
-        return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "hypercube index out of range");
-    }
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    HIP_TRY(dtype == NDZIP_HIP_F32 ? launch_debug_stage<float>(stage, dims, gg, hc, d_in, d_out, d_out_len, n, aligned, s)
-                                   : launch_debug_stage<double>(stage, dims, gg, hc, d_in, d_out, d_out_len, n, aligned, s));
     return NDZIP_HIP_OK;
 }
 

@@ -7,7 +7,8 @@
 //                      entries, stream length.  Replaces compress_block + hierarchical_inclusive_scan (2 kernels x
 //                      levels) + compact_all_chunks + store_stream_length (:401-457,:507-511, cuda_bits.cuh:266-333).
 //   decompress_kernel  one tile per workgroup, header lookup -> LDS -> decode (replaces decompress_block :477-492).
-//   debug_stage_kernel single-hypercube stage entry points for the parity tests.
+//   debug_*_kernel     single-hypercube stage entry points for the parity tests: compiled only with NDZIP_STAGE_KERNELS, i.e. into
+//                      libndzip_hip_stages.so (stages_f32.hip / stages_f64.hip) -- the product library holds none of them.
 
 #include <cstdio>
 #include <cstdlib>
@@ -865,6 +866,7 @@ decompress_kernel_wide(const uint32_t *__restrict__ header, const uint32_t *__re
     wide::inverse_transform<Dims, Aligned>(r, out, gg, active ? hc_origin<Dims>(gg, hc) : 0, active, cube, smem, t);
 }
 
+#ifdef NDZIP_STAGE_KERNELS
 // ---- stage kernels for the parity tests: exactly one hypercube, through the SAME device functions the production kernels
 // call (mirror of the reference's stage tests, src/test/codec_profile_test.inl:514-549, :552-729, :735-801, :889-947) --------
 
@@ -1064,6 +1066,8 @@ debug_lookback_kernel(const uint32_t *__restrict__ lengths, uint32_t *__restrict
     release_tickets(tickets, num_classes, lane, err, total);
 }
 
+#endif  // NDZIP_STAGE_KERNELS
+
 // ---- launchers ----------------------------------------------------------------------------------------------------------
 
 // persistent grid, fully resident: workgroups per CU bounded by the occupancy query and by what the LDS alone admits
@@ -1167,6 +1171,7 @@ hipError_t launch_decompress_profile(const decompress_args &a) {
     return hipGetLastError();
 }
 
+#ifdef NDZIP_STAGE_KERNELS
 template<typename T, int Dims, bool Aligned>
 hipError_t launch_debug_profile(int stage, const grid_geom &gg, uint32_t hc, const void *in, void *out, uint32_t *out_len,
         hipStream_t stream) {
@@ -1189,6 +1194,8 @@ hipError_t launch_debug_profile(int stage, const grid_geom &gg, uint32_t hc, con
     return hipGetLastError();
 }
 
+#endif  // NDZIP_STAGE_KERNELS
+
 #define NDZIP_DISPATCH(FN, dims, aligned, ...)                                          \
     switch (dims) {                                                                     \
         case 1: return (aligned) ? FN<T_, 1, true>(__VA_ARGS__) : FN<T_, 1, false>(__VA_ARGS__); \
@@ -1199,6 +1206,7 @@ hipError_t launch_debug_profile(int stage, const grid_geom &gg, uint32_t hc, con
 
 }  // namespace
 
+#ifndef NDZIP_STAGE_KERNELS
 template<>
 int compress_hcs_per_group<T_>(int) {
     return tile_cfg<T_, 1>::K;
@@ -1219,6 +1227,7 @@ hipError_t launch_decompress<T_>(int dims, const decompress_args &a) {
     NDZIP_DISPATCH(launch_decompress_profile, dims, a.aligned, a)
 }
 
+#else  // NDZIP_STAGE_KERNELS: the stage library (stages_f32.hip / stages_f64.hip) gets the stage entry point and nothing else
 template<>
 hipError_t launch_debug_stage<T_>(int stage, int dims, const grid_geom &gg, uint32_t hc, const void *in, void *out,
         uint32_t *out_len, uint32_t n, bool aligned, hipStream_t stream) {
@@ -1262,6 +1271,8 @@ hipError_t launch_debug_stage<T_>(int stage, int dims, const grid_geom &gg, uint
     }
     NDZIP_DISPATCH(launch_debug_profile, dims, aligned, stage, gg, hc, in, out, out_len, stream)
 }
+
+#endif  // NDZIP_STAGE_KERNELS
 
 #undef NDZIP_DISPATCH
 

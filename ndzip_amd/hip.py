@@ -25,6 +25,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libndzip_hip.so")  # (A/B tooling assigns this before the first lib() call; no environment override)
+STAGES_LIB_PATH = os.path.join(_HERE, "libndzip_hip_stages.so")  # test hooks (debug_stage): never loaded by the product path
 
 F32, F64 = 0, 1
 
@@ -39,6 +40,7 @@ ERR_LIMIT = -7
 
 _U32P = C.POINTER(C.c_uint32)
 _lib = None
+_stages_lib = None
 
 # every symbol include/ndzip_hip.h declares (the CPU test suite checks the library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -77,8 +79,9 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_chunked_plan",
     "ndzip_hip_chunked_compress",
     "ndzip_hip_chunked_decompress",
-    "ndzip_hip_debug_stage",
 )
+# include/ndzip_hip_stages.h: the parity tests' stage entry point lives in a library of its own (the product library holds no stage kernel)
+STAGE_SYMBOLS = ("ndzip_hip_stages_last_error", "ndzip_hip_debug_stage")
 
 
 class NdzipHipError(RuntimeError):
@@ -104,6 +107,26 @@ def lib():
         pass
     _lib = _bind(C.CDLL(LIB_PATH))
     return _lib
+
+
+def _bind_stages(L):
+    L.ndzip_hip_stages_last_error.restype = C.c_char_p
+    L.ndzip_hip_stages_last_error.argtypes = []
+    L.ndzip_hip_debug_stage.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ndzip_hip_debug_stage.restype = C.c_int
+    return L
+
+
+def stages_lib():
+    """libndzip_hip_stages.so (include/ndzip_hip_stages.h): loaded by the parity tests' debug_stage() only."""
+    global _stages_lib
+    if _stages_lib is not None:
+        return _stages_lib
+    if not os.path.exists(STAGES_LIB_PATH):
+        raise FileNotFoundError(f"{STAGES_LIB_PATH} is missing: build it with `python -m ndzip_amd.build`")
+    lib()  # (loads the HIP runtime the way the product library does)
+    _stages_lib = _bind_stages(C.CDLL(STAGES_LIB_PATH))
+    return _stages_lib
 
 
 class _Tolerant:
@@ -169,7 +192,6 @@ def _bind(L, strict: bool = True):
     L.ndzip_hip_chunked_plan.argtypes = [C.c_int, C.c_int, _U64P, C.c_uint64, _U64P, _U64P, _U64P]
     L.ndzip_hip_chunked_compress.argtypes = [C.c_int, C.c_int, _U64P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, _U64P, _U64P]
     L.ndzip_hip_chunked_decompress.argtypes = [C.c_int, C.c_int, _U64P, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, _U64P, _U64P]
-    L.ndzip_hip_debug_stage.argtypes = [C.c_int, C.c_int, C.c_int, _U32P, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name != "ndzip_hip_last_error":
             getattr(L, name).restype = C.c_int
@@ -528,6 +550,9 @@ def make_hip_offloader(dtype, dims: int) -> HipOffloader:
 
 
 def debug_stage(stage: int, dtype, dims: int, extent, hc: int, d_in, d_out, d_out_len=None, n: int = 0, stream: int = 0) -> None:
+    """Parity-test hook (include/ndzip_hip_stages.h, libndzip_hip_stages.so): one hypercube through one stage of the kernels."""
     ext = _ext(extent) if extent is not None else None
-    _check(lib().ndzip_hip_debug_stage(stage, _dtype_code(dtype), dims, ext, hc, _ptr(d_in), _ptr(d_out), _ptr(d_out_len), n,
-                                       C.c_void_p(stream or None)))
+    L = stages_lib()
+    status = L.ndzip_hip_debug_stage(stage, _dtype_code(dtype), dims, ext, hc, _ptr(d_in), _ptr(d_out), _ptr(d_out_len), n, C.c_void_p(stream or None))
+    if status != OK:
+        raise NdzipHipError(status, L.ndzip_hip_stages_last_error().decode() or f"ndzip_hip status {status}")

@@ -1,4 +1,4 @@
-"""CPU suite: the C-ABI library loads, exports every symbol include/ndzip_hip.h declares, its host-side sizing logic
+"""CPU suite: the C-ABI libraries load, export every symbol include/ndzip_hip.h / ndzip_hip_stages.h declare, its host-side sizing logic
 matches the oracle, and -- without a GPU -- every compute entry point fails loudly (there is no CPU fallback)."""
 import os
 import re
@@ -14,8 +14,8 @@ from oracle import oracle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ndzip_hip.h")).read()
+def _declared_symbols(header="ndzip_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     return sorted(set(re.findall(r"NDZIP_HIP_API[^;(]*?\b(ndzip_hip_\w+)\s*\(", text)))
 
 
@@ -29,6 +29,23 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (ndzip_hip_\w+)", out))
     assert exported == set(declared), f"unexpected exports: {exported ^ set(declared)}"
+
+
+def test_stage_hooks_live_in_a_library_of_their_own():
+    """include/ndzip_hip_stages.h (the parity tests' single-hypercube stage entry point) is exported by libndzip_hip_stages.so and by
+    nothing else: the product library holds neither the entry point nor a stage kernel."""
+    declared = _declared_symbols("ndzip_hip_stages.h")
+    assert sorted(hip.STAGE_SYMBOLS) == declared == ["ndzip_hip_debug_stage", "ndzip_hip_stages_last_error"]
+    out = subprocess.run(["nm", "-D", "--defined-only", hip.STAGES_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert set(re.findall(r" T (ndzip_hip_\w+)", out)) == set(declared)
+    S = hip.stages_lib()
+    for name in declared:
+        assert getattr(S, name) is not None
+    for path, want in ((hip.LIB_PATH, False), (hip.STAGES_LIB_PATH, True)):
+        blob = open(path, "rb").read()
+        assert (b"debug_stage_kernel" in blob) == want and (b"debug_lookback_kernel" in blob) == want, path
+    blob = open(hip.STAGES_LIB_PATH, "rb").read()  # ... and the stage library holds no production kernel
+    assert b"compress_kernel_db" not in blob and b"decompress_kernel" not in blob and b"compress_kernel_wide" not in blob
 
 
 def test_library_contains_gfx950_code_object():
@@ -231,16 +248,16 @@ def test_exec_masked_plane_compaction_has_the_shape_it_was_written_in(tmp_path):
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("no llvm-objdump")
-    lib = shutil.copy(hip.LIB_PATH, tmp_path / "lib.so")
-    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, capture_output=True, text=True, check=True)
-    text = ""
-    for f in sorted(os.listdir(tmp_path)):
-        if "gfx950" in f:
-            text += subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
-    ins = [line.split("\t")[1].split("//")[0].strip() for line in text.splitlines() if line.startswith("\t") and len(line.split("\t")) > 1 and line.split("\t")[1].strip()]
+    from tests import gfx9_interp as gi
+
+    # the product library (7 instantiations of compress_kernel_db, loop and drain) and the stage library (the f32 encode stage
+    # kernels: 3 dims x aligned / unaligned), 32 planes per sequence
+    ins = []
+    for k, path in enumerate((hip.LIB_PATH, hip.STAGES_LIB_PATH)):
+        os.makedirs(tmp_path / str(k))
+        ins += gi.disassemble(path, str(tmp_path / str(k)))
     at = [i for i, s in enumerate(ins) if s.startswith("v_cmpx_ne_u32")]
-    # 7 instantiations of compress_kernel_db + the f32 encode stage kernels (3 dims x aligned / unaligned), 32 planes each
-    assert len(at) % 32 == 0 and len(at) >= 7 * 32, len(at)
+    assert len(at) % 32 == 0 and len(at) >= (14 + 6) * 32, len(at)
     for n, i in enumerate(at):
         m = re.match(r"v_cmpx_ne_u32_e32 vcc, 0, (v\d+)$", ins[i])
         assert m, ins[i]
@@ -273,13 +290,16 @@ def test_exec_masked_plane_compaction_executes_correctly_under_any_entry_mask(tm
 
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("no llvm-objdump")
-    ins = gi.disassemble(hip.LIB_PATH, str(tmp_path))
+    ins = []
+    for k, path in enumerate((hip.LIB_PATH, hip.STAGES_LIB_PATH)):  # (product kernels and the f32 encode stage kernels)
+        os.makedirs(tmp_path / str(k))
+        ins += gi.disassemble(path, str(tmp_path / str(k)))
     heads = []
     for i, s in enumerate(ins):
         m = re.fullmatch(r"s_mov_b64 (s\[\d+:\d+\]), exec", s)
         if m and any(x.startswith("v_cmpx_ne_u32") for x in ins[i + 1:i + 4]):
             heads.append((i, m.group(1)))
-    assert len(heads) >= 13, len(heads)  # 7 compress_kernel_db instantiations + 6 f32 encode stage kernels
+    assert len(heads) >= 20, len(heads)  # 7 compress_kernel_db instantiations (loop + drain) + 6 f32 encode stage kernels
     rng = np.random.default_rng(20260929)
     for n, (start, saved) in enumerate(heads):
         # the sequence: up to and including the 4th "s_nop 1" that closes an asm statement

@@ -21,12 +21,12 @@ CXX = os.environ.get("WAVESIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-std=c++17", "-O1", "-g0", "-fPIC", "-pthread", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unknown-attributes",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-const-variable"]
 FLAGS += os.environ.get("WAVESIM_EXTRA_FLAGS", "").split()
-UNITS = ["kernels_f32.hip", "kernels_f64.hip", "capi.hip"]
+UNITS = ["kernels_f32.hip", "kernels_f64.hip", "capi.hip", "stages_f32.hip", "stages_f64.hip", "stages_capi.hip"]  # (product + stage hooks in ONE model library)
 
 
 def _sources():
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".inl"))]
-    files += [os.path.join(ROOT, "include", "ndzip_hip.h")]
+    files += [os.path.join(ROOT, "include", "ndzip_hip.h"), os.path.join(ROOT, "include", "ndzip_hip_stages.h")]
     files += [os.path.join(HERE, f) for f in ("gfx950_lds.hpp", "wavesim.cc", os.path.join("hip", "hip_runtime.h"), "build.py")]
     return files
 
@@ -75,7 +75,8 @@ def _build_locked(OUT, BUILD, FLAGS, verbose, extra_flags, kernel_flags) -> str:
         if f.endswith((".hip", ".hpp", ".inl")):
             shutil.copy(os.path.join(CSRC, f), os.path.join(src, f))
     shutil.copy(os.path.join(HERE, "gfx950_lds.hpp"), os.path.join(src, "gfx950_lds.hpp"))
-    shutil.copy(os.path.join(ROOT, "include", "ndzip_hip.h"), os.path.join(BUILD, "include", "ndzip_hip.h"))
+    for h in ("ndzip_hip.h", "ndzip_hip_stages.h"):
+        shutil.copy(os.path.join(ROOT, "include", h), os.path.join(BUILD, "include", h))
 
     def compile_one(job):
         source, obj = job

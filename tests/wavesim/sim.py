@@ -25,7 +25,8 @@ def load(variant: str = "", defines=()):
         kflags = simbuild.LDSPROF_FLAGS if variant == "ldsprof" else ()
         if variant == "ldsprof":
             defines = tuple(defines) + ("WAVESIM_LDSPROF",)
-        _sim[variant] = hip._bind(C.CDLL(simbuild.build(variant=variant, defines=defines, extra_flags=flags, kernel_flags=kflags)))
+        # (one model library holds the product entry points and the stage hooks: bound for both)
+        _sim[variant] = hip._bind_stages(hip._bind(C.CDLL(simbuild.build(variant=variant, defines=defines, extra_flags=flags, kernel_flags=kflags))))
     return _sim[variant]
 
 
@@ -34,15 +35,15 @@ def active(cus: int = 2, blocks_per_cu: int = 2, variant: str = "", schedule: st
     """Route ndzip_amd.hip's ctypes calls to the model for the duration of the block (tests only: the product never does).
     schedule: order in which a workgroup's runnable work-items are resumed: "" (forward), "reverse", "random:<seed>"."""
     L = load(variant)
-    saved, env = hip._lib, {k: os.environ.get(k) for k in ("WAVESIM_CUS", "WAVESIM_BLOCKS_PER_CU", "WAVESIM_SCHEDULE")}
+    saved, saved_stages, env = hip._lib, hip._stages_lib, {k: os.environ.get(k) for k in ("WAVESIM_CUS", "WAVESIM_BLOCKS_PER_CU", "WAVESIM_SCHEDULE")}
     os.environ["WAVESIM_CUS"] = str(cus)
     os.environ["WAVESIM_BLOCKS_PER_CU"] = str(blocks_per_cu)
     os.environ["WAVESIM_SCHEDULE"] = schedule
-    hip._lib = L
+    hip._lib = hip._stages_lib = L
     try:
         yield L
     finally:
-        hip._lib = saved
+        hip._lib, hip._stages_lib = saved, saved_stages
         for k, v in env.items():
             if v is None:
                 os.environ.pop(k, None)
