@@ -64,6 +64,11 @@ struct launch_cfg {
 constexpr size_t lds_capacity = 160 * 1024;
 // runs fn(arg) once per work-item of grid x block; workgroups are co-resident up to WAVESIM_MAX_RESIDENT (default 32)
 void run_grid(launch_cfg cfg, void (*fn)(void *), void *arg);
+// Launch interception (tests/gfx950_exec.py: the built gfx950 code object executed instead of the host-compiled kernel): called
+// with the kernel's host function, the launch configuration and the explicit kernel arguments packed as the HSA kernarg ABI lays
+// them out (each at its natural alignment); returns true when it has run the grid itself.  Not set = the model runs it.
+using launch_hook_t = int (*)(const void *kernel, unsigned grid, unsigned block, unsigned lds_bytes, const void *args, unsigned args_bytes);
+launch_hook_t launch_hook();
 
 }  // namespace wavesim
 
@@ -296,9 +301,22 @@ inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, s
 #include <tuple>
 #include <utility>
 
+template<typename T>
+inline void wavesim_pack_kernarg(unsigned char *buf, size_t &at, const T &v) {
+    at = (at + alignof(T) - 1) / alignof(T) * alignof(T);
+    std::memcpy(buf + at, &v, sizeof(T));
+    at += sizeof(T);
+}
+
 template<typename... Params, typename... Args>
 inline void wavesim_launch(void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds_bytes, Args &&...args) {
     std::tuple<std::decay_t<Params>...> bound{static_cast<std::decay_t<Params>>(std::forward<Args>(args))...};
+    if (const auto hook = wavesim::launch_hook()) {
+        alignas(16) unsigned char buf[(sizeof(std::decay_t<Params>) + ... + 0) + 16 * sizeof...(Params) + 16] = {};
+        size_t at = 0;
+        std::apply([&](const auto &...v) { (wavesim_pack_kernarg(buf, at, v), ...); }, bound);
+        if (hook(reinterpret_cast<const void *>(kernel), grid.x, block.x, static_cast<unsigned>(lds_bytes), buf, static_cast<unsigned>(at))) return;
+    }
     struct thunk_t {
         void (*kernel)(Params...);
         std::tuple<std::decay_t<Params>...> *bound;

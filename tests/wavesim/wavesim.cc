@@ -578,6 +578,13 @@ WAVESIM_HOOK(__sanitizer_cov_store4, 4, true)
 WAVESIM_HOOK(__sanitizer_cov_store8, 8, true)
 WAVESIM_HOOK(__sanitizer_cov_store16, 16, true)
 
+// launch interception (hip/hip_runtime.h: launch_hook_t)
+namespace wavesim {
+static std::atomic<launch_hook_t> g_launch_hook{nullptr};
+launch_hook_t launch_hook() { return g_launch_hook.load(); }
+}  // namespace wavesim
+extern "C" __attribute__((visibility("default"))) void wavesim_set_launch_hook(wavesim::launch_hook_t hook) { wavesim::g_launch_hook.store(hook); }
+
 // the profile so far as JSON lines "offset-in-library bytes store instructions cycles ideal lanes", then cleared
 extern "C" __attribute__((visibility("default"))) int wavesim_lds_profile_dump(const char *path) {
     FILE *f = fopen(path, "w");
