@@ -496,6 +496,13 @@ def _(w, i):
     w.scc = int(r != 0)
 
 
+@op("s_not_b32")
+def _(w, i):
+    r = ~w.rs32(i.args[1]) & M32
+    w.ws32(i.args[0], r)
+    w.scc = int(r != 0)
+
+
 @op("s_not_b64")
 def _(w, i):
     r = ~w.rs64(i.args[1]) & M64
@@ -1006,7 +1013,8 @@ _reg("v_cvt_u32_f32", 1, _cvt_u32_f32)
 @op("v_fmac_f32_e32", "v_fmac_f32_e64", "v_fmac_f32")
 def _(w, i):
     n = int(_RE_V.match(i.args[0]).group(1))
-    r = (_f(w.rv32(i.args[1])).astype(np.float64) * _f(w.rv32(i.args[2])).astype(np.float64) + _f(w.v[n]).astype(np.float64)).astype(np.float32)
+    with np.errstate(all="ignore"):  # (lanes outside EXEC hold junk)
+        r = (_f(w.rv32(i.args[1])).astype(np.float64) * _f(w.rv32(i.args[2])).astype(np.float64) + _f(w.v[n]).astype(np.float64)).astype(np.float32)
     w.wv32(i.args[0], _fu(r))
 
 
@@ -1272,7 +1280,7 @@ class Kernel:
         self.missing = sorted({x.op for x in self.code.values() if x.fn is None})
 
 
-def run_grid(kernel: Kernel, grid: int, block: int, dynamic_lds: int, explicit_args: bytes, resident: int = 8, quantum: int = 4000,
+def run_grid(kernel: Kernel, grid: int, block: int, dynamic_lds: int, explicit_args: bytes, resident: int = 8, quantum=4000,
              max_instructions: int = 400_000_000, trace=None):
     """Execute `grid` workgroups of `block` work-items.  At most `resident` workgroups are in flight at a time and are started in
     blockIdx order; their wavefronts are interleaved round-robin, `quantum` instructions at a time (and at every s_sleep /
@@ -1346,7 +1354,8 @@ def run_grid(kernel: Kernel, grid: int, block: int, dynamic_lds: int, explicit_a
                 w.state = Wave.RUNNING
                 n = 0
                 code = w.code
-                while w.state == Wave.RUNNING and n < quantum:
+                q = quantum(wg.index) if callable(quantum) else quantum  # (a function of the workgroup: adversarial schedules)
+                while w.state == Wave.RUNNING and n < q:
                     ins = code[w.pc]
                     w.pc += ins.size
                     if trace is not None:

@@ -265,6 +265,27 @@ def test_hazard_checker_fires_on_what_it_is_meant_to_catch():
     assert run(["v_readfirstlane_b32 s9, v0", "s_nop 3", "v_readlane_b32 s3, v5, s9"]) == []
 
 
+def test_lookback_timeout_path_of_the_code_object(tmp_path, monkeypatch):
+    """tests/test_wavesim_codec.py::test_lookback_timeout_stays_in_bounds_and_is_reported on the interpreted spin-limit-0 build
+    (ndzip_amd/_variants/spin0.so): the give-up path as compiled -- partial prefix from published lengths only (the canary behind
+    the caller's buffer stays intact), error word through the returning atomic, stream length poisoned by the last workgroup out."""
+    from ndzip_amd import build
+    from tests import test_wavesim_codec as ct
+
+    build.build_test_variants()
+    spin0 = os.path.join(os.path.dirname(hip.LIB_PATH), "_variants", "spin0.so")
+    model = simbuild.build(variant="spin0", defines=("NDZIP_LOOKBACK_SPIN_LIMIT=0",))
+    real = gx.run_grid
+    # an adversarial schedule: workgroup 1 gets 40 instructions per turn, the others 3 000 -- it draws one of the first tickets like
+    # everybody else and then crawls, so its tile is published long after the successors looked for it: their look-backs have to
+    # wait, which this build turns into a time-out at once
+    monkeypatch.setattr(gx, "run_grid", lambda *a, **k: real(*a, **{**k, "quantum": lambda wg: 40 if wg == 1 else 3000}))
+    b = gx.Bridge(model, [spin0], str(tmp_path))
+    with b:
+        ct.test_lookback_timeout_stays_in_bounds_and_is_reported()
+    assert sum("compress_kernel_db" in n for n, *_ in b.launched) >= 2
+
+
 def test_no_wait_state_hazard_in_any_executed_stream():
     """(last in this module) every instruction the tests above executed went through the hazard rules: nothing reported -- in
     particular not at the boundaries of the inline assembly, which the compiler's own hazard recogniser cannot see into"""
