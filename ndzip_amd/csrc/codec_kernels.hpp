@@ -913,21 +913,30 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
             }
         }
     } else if constexpr (Dims == 2) {
-        // work-item = column x of one half of the rows; the second half first accumulates the first half
-        const uint32_t x = static_cast<uint32_t>(t) & 63u;
-        const int half = t >> 6;
+        // work-item = column x of one half of the rows; the second half first accumulates the first half.
+        // A row is 64 values = two padded chunks, so value (y, x) sits at off(x) + y * off(64): ONE per-lane LDS address with the
+        // row in the instruction's offset field, ONE running scalar pointer for the hypercube's rows in global memory and one
+        // per-lane offset register (the loop used to rebuild all three per row: ~10 VALU instructions and two v_readfirstlane
+        // for each of its 32 rows -- the executed-instruction profile showed the 2D f32 decoder at 1 801 VALU per hypercube
+        // against 1 358 / 1 237 for 3D / 1D).
+        const uint32_t x = static_cast<uint32_t>(lane);
+        constexpr uint32_t row_bytes = L::off(64);
+        const uint32_t y0 = wave ? 32u : 0u;  // (wave-uniform)
+        const char *src = cube + L::off(x);
         W acc = 0;
-        if (half) {
+        if (wave) {
 #pragma unroll 8
-            for (uint32_t y = 0; y < 32; ++y) acc += lds_read<W>(cube, L::off(y * 64 + x));
+            for (uint32_t y = 0; y < 32; ++y) acc += lds_read<W>(src, y * row_bytes);
         }
-        const uint32_t y0 = half ? 32u : 0u;
+        src += y0 * row_bytes;
+        char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin + static_cast<uint64_t>(y0) * gg.stride[0]));
+        const uint64_t row_step = gg.stride[0] * sizeof(W);
+        const uint32_t lane_bytes = lane_offset_here(x * static_cast<uint32_t>(sizeof(W)));
 #pragma unroll 8
-        for (uint32_t y = y0; y < y0 + 32; ++y) {
-            acc += lds_read<W>(cube, L::off(y * 64 + x));
-            // (uniform: the hypercube's row y; per lane: the column)
-            *reinterpret_cast<W *>(reinterpret_cast<char *>(scalar_pointer(out + origin + static_cast<uint64_t>(y) * gg.stride[0]))
-                    + lane_offset_here(x * static_cast<uint32_t>(sizeof(W)))) = rotr1(acc);
+        for (uint32_t y = 0; y < 32; ++y) {
+            acc += lds_read<W>(src, y * row_bytes);
+            *reinterpret_cast<W *>(dst + lane_bytes) = rotr1(acc);
+            dst = scalar_pointer(dst + row_step);
         }
     } else {
         // work-item = (y, pair of x) for all 16 z

@@ -432,15 +432,24 @@ NDZIP_DEV void inverse_transform(uint64_t (&r)[vals], uint64_t *__restrict__ out
         for (int j = 0; j < vals; ++j) r[j] += left;
     } else {
         // work-item = row (z, y) = (t / 16, t % 16): the 16 rows of a z-plane are the 16 lanes of a DPP row -- y is a plain row
-        // scan, no masks (lanes shifted in from outside the row read as 0)
+        // scan, no masks (lanes shifted in from outside the row read as 0).  Two instructions per value and step
+        // (v_add_co_u32_dpp + v_addc_co_u32_dpp, gfx950_lds.hpp: row_scan_step64) where the compiled form takes three.
+        uint32_t lo[2][8], hi[2][8];
 #pragma unroll
-        for (int j = 0; j < vals; ++j) r[j] += row_shift_up<1>(r[j]);
+        for (int j = 0; j < vals; ++j) {
+            lo[j >> 3][j & 7] = static_cast<uint32_t>(r[j]);
+            hi[j >> 3][j & 7] = static_cast<uint32_t>(r[j] >> 32);
+        }
+        row_scan_step64<1>(lo[0], hi[0]);
+        row_scan_step64<1>(lo[1], hi[1]);
+        row_scan_step64<2>(lo[0], hi[0]);
+        row_scan_step64<2>(lo[1], hi[1]);
+        row_scan_step64<4>(lo[0], hi[0]);
+        row_scan_step64<4>(lo[1], hi[1]);
+        row_scan_step64<8>(lo[0], hi[0]);
+        row_scan_step64<8>(lo[1], hi[1]);
 #pragma unroll
-        for (int j = 0; j < vals; ++j) r[j] += row_shift_up<2>(r[j]);
-#pragma unroll
-        for (int j = 0; j < vals; ++j) r[j] += row_shift_up<4>(r[j]);
-#pragma unroll
-        for (int j = 0; j < vals; ++j) r[j] += row_shift_up<8>(r[j]);
+        for (int j = 0; j < vals; ++j) r[j] = (static_cast<uint64_t>(hi[j >> 3][j & 7]) << 32) | lo[j >> 3][j & 7];
     }
 
     __syncthreads();  // every work-item has consumed the encoded run: overwrite `cube` with values

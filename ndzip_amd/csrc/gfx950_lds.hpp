@@ -207,6 +207,37 @@ NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
 #undef NDZIP_APPEND8
 #undef NDZIP_APPEND1
 
+// One step of a prefix sum over the 16 lanes of a DPP row for EIGHT 64-bit values held as (lo, hi) register pairs:
+// v += row_shr:D(v), lanes shifted in from outside the row contributing 0.  In C++ this is two v_mov_b32_dpp and a 64-bit add per
+// value (the DPP move folds into a plain v_add_u32, not into an add that produces or consumes a carry): 3 VALU instructions; here
+// v_add_co_u32_dpp + v_addc_co_u32_dpp: 2.  (f64 3D decode: 64 value-steps per work-item.)
+// Wait states: a DPP instruction must not read a VGPR a VALU instruction wrote less than 2 wait states earlier, and the compiler
+// does not look into an asm statement -- each statement opens with s_nop 1; inside, consecutive instructions touch different
+// registers (lo_j, hi_j, lo_j+1 ...), and a value's next step is at least 16 instructions away.  VCC is clobbered.
+#define NDZIP_ROWADD1(n, d) \
+    "v_add_co_u32_dpp %[l" #n "], vcc, %[l" #n "], %[l" #n "] row_shr:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_addc_co_u32_dpp %[h" #n "], vcc, %[h" #n "], %[h" #n "], vcc row_shr:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define NDZIP_ROWADD8(d) "s_nop 1\n\t" NDZIP_ROWADD1(0, d) NDZIP_ROWADD1(1, d) NDZIP_ROWADD1(2, d) NDZIP_ROWADD1(3, d) NDZIP_ROWADD1(4, d) NDZIP_ROWADD1(5, d) NDZIP_ROWADD1(6, d) NDZIP_ROWADD1(7, d)
+#define NDZIP_ROWADD_OPERANDS \
+    [l0] "+v"(lo[0]), [h0] "+v"(hi[0]), [l1] "+v"(lo[1]), [h1] "+v"(hi[1]), [l2] "+v"(lo[2]), [h2] "+v"(hi[2]), [l3] "+v"(lo[3]), [h3] "+v"(hi[3]), \
+    [l4] "+v"(lo[4]), [h4] "+v"(hi[4]), [l5] "+v"(lo[5]), [h5] "+v"(hi[5]), [l6] "+v"(lo[6]), [h6] "+v"(hi[6]), [l7] "+v"(lo[7]), [h7] "+v"(hi[7])
+template<int D>
+NDZIP_DEV void row_scan_step64(uint32_t (&lo)[8], uint32_t (&hi)[8]) {
+    static_assert(D == 1 || D == 2 || D == 4 || D == 8);
+    if constexpr (D == 1) {
+        asm volatile(NDZIP_ROWADD8(1) : NDZIP_ROWADD_OPERANDS : : "vcc");
+    } else if constexpr (D == 2) {
+        asm volatile(NDZIP_ROWADD8(2) : NDZIP_ROWADD_OPERANDS : : "vcc");
+    } else if constexpr (D == 4) {
+        asm volatile(NDZIP_ROWADD8(4) : NDZIP_ROWADD_OPERANDS : : "vcc");
+    } else {
+        asm volatile(NDZIP_ROWADD8(8) : NDZIP_ROWADD_OPERANDS : : "vcc");
+    }
+}
+#undef NDZIP_ROWADD_OPERANDS
+#undef NDZIP_ROWADD8
+#undef NDZIP_ROWADD1
+
 // The stores of lds_append_nonzero are invisible to the compiler's s_waitcnt bookkeeping (inline asm is opaque to it): the
 // workgroup barrier behind which other wavefronts read the compacted run must be preceded by this explicit wait.  (In the builds
 // looked at the compiler had an lgkmcnt(0) of its own in front of that barrier -- for the chunk head it stores itself -- but

@@ -854,6 +854,10 @@ def _carry_op(sub, rev, with_carry_in):
         # vD, carry-out (vcc | s[a:b]), src0, src1 [, carry-in]
         a = np.broadcast_to(np.asarray(w.rv32(i.args[2]), dtype=np.uint32), (64,)).astype(np.uint64)
         b = np.broadcast_to(np.asarray(w.rv32(i.args[3]), dtype=np.uint32), (64,)).astype(np.uint64)
+        mask = None
+        if i.op.endswith("_dpp"):  # (DPP permutes src0)
+            a32, mask = _dpp_source(w, i, a.astype(np.uint32))
+            a = a32.astype(np.uint64)
         if rev:
             a, b = b, a
         cin = mask_of(w.rs64(i.args[4])).astype(np.uint64) if with_carry_in else np.uint64(0)
@@ -863,12 +867,12 @@ def _carry_op(sub, rev, with_carry_in):
         else:
             r = a + b + cin
             carry = r > np.uint64(M32)
-        w.wv32(i.args[0], (r & np.uint64(M32)).astype(np.uint32))
+        w.wv32(i.args[0], (r & np.uint64(M32)).astype(np.uint32), mask)
         w.wmask(i.args[1], carry)
     return h
 
 
-for _s in ("_e32", "_e64"):
+for _s in ("_e32", "_e64", "_dpp"):
     OPS["v_add_co_u32" + _s] = _carry_op(False, False, False)
     OPS["v_sub_co_u32" + _s] = _carry_op(True, False, False)
     OPS["v_subrev_co_u32" + _s] = _carry_op(True, True, False)
@@ -1195,6 +1199,7 @@ OPS["global_atomic_swap_x2"] = _gatomic(lambda c, d: d, 2)
 # = one wait state, s_nop N = N + 1.  Checked on the EXECUTED instruction stream, per wavefront; compiler-scheduled code must come
 # out clean too (it does: that calibrates the rules).
 HAZARD_LOG = []
+PROFILE = None  # tools/dynamic_profile.py: a collections.Counter of (kernel, opcode) -> wave-instructions EXECUTED
 
 
 def _regs_of(tok, kind):
@@ -1361,6 +1366,8 @@ def run_grid(kernel: Kernel, grid: int, block: int, dynamic_lds: int, explicit_a
                     if trace is not None:
                         trace(w, ins)
                     check_hazards(w, ins)
+                    if PROFILE is not None:
+                        PROFILE[(kernel.name, ins.op)] += 1
                     try:
                         ins.fn(w, ins)
                     except Unsupported:

@@ -122,4 +122,16 @@ NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
 
 NDZIP_DEV void lds_append_complete() {}
 
+// v += row_shr:D(v) for eight 64-bit values as (lo, hi) pairs (product: v_add_co_u32_dpp + v_addc_co_u32_dpp in assembly)
+template<int D>
+NDZIP_DEV void row_scan_step64(uint32_t (&lo)[8], uint32_t (&hi)[8]) {
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t sl = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo[j]), 0x110 + D, 0xf, 0xf, true));
+        const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi[j]), 0x110 + D, 0xf, 0xf, true));
+        const uint64_t r = ((static_cast<uint64_t>(hi[j]) << 32) | lo[j]) + ((static_cast<uint64_t>(sh) << 32) | sl);
+        lo[j] = static_cast<uint32_t>(r);
+        hi[j] = static_cast<uint32_t>(r >> 32);
+    }
+}
+
 }  // namespace ndzip_hip

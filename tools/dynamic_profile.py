@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Executed-instruction profile of the BUILT kernels WITHOUT a GPU (test tooling; tests/gfx950_exec.py interprets the gfx950 code objects):
+wave-instructions actually executed per hypercube, by class, for the compress and the decompress kernel of a profile on the
+benchmark's synthetic data -- the dynamic counterpart of tools/isa_cost.py, whose static counts include both sides of every branch
+(dense-chunk paths, look-back retry loops, the drain).  VALU issue cycles per hypercube and SIMD = VALU x 4 / 4 SIMDs x wavefronts.
+
+usage: dynamic_profile.py [--dtype float32] [--shape 32,64,64] [--noise-mask 0xff] [--f64-work-items 0|128|256]"""
+import argparse
+import collections
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def klass(op):
+    if op.startswith("v_"):
+        return "VALU"
+    if op.startswith("ds_"):
+        return "LDS"
+    if op.startswith("global_"):
+        return "VMEM"
+    if op.startswith(("s_cbranch", "s_branch")):
+        return "branch"
+    if op in ("s_waitcnt", "s_nop", "s_barrier", "s_sleep"):
+        return op
+    return "SALU"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--shape", default="32,64,64")
+    ap.add_argument("--noise-mask", type=lambda s: int(s, 0), default=0xFF)
+    ap.add_argument("--f64-work-items", type=int, default=0)
+    a = ap.parse_args()
+    from ndzip_amd import hip, synth
+    from oracle import oracle
+    from tests import gfx950_exec as gx
+    from tests.wavesim import build as simbuild
+    from tests.wavesim import sim
+
+    shape = tuple(int(x) for x in a.shape.split(","))
+    dt = np.dtype(a.dtype).type
+    data = synth.synth_numpy(shape, dt, seed=1, noise_mask=a.noise_mask)
+    want = oracle.compress(data)
+    nhc = hip.num_hypercubes(shape)
+    gx.PROFILE = collections.Counter()
+    bridge = gx.Bridge(simbuild.build(), [hip.LIB_PATH], tempfile.mkdtemp(prefix="gfx950_prof"))
+    with bridge:
+        got = sim.compress(data, cus=4, blocks_per_cu=2)
+        back = sim.decompress(want, dt, shape, f64_work_items=a.f64_work_items)
+    assert np.array_equal(got, want) and np.array_equal(back.view(np.uint8), data.view(np.uint8))
+    ratio = want.nbytes / data.nbytes
+    print(f"# executed wave-instructions per hypercube: {a.dtype} {'x'.join(map(str, shape))}, {nhc} hypercubes, ratio {ratio:.3f}"
+          + (f", f64 decoder with {a.f64_work_items} work-items" if a.f64_work_items else ""))
+    for name, grid, block, total in bridge.launched:
+        if "border" in name:
+            continue
+        per = collections.Counter()
+        for (k, op), n in gx.PROFILE.items():
+            if k == name:
+                per[klass(op)] += n
+        short = name.split("N_1")[1][2:44]
+        waves_per_hc = {True: 4, False: 2}["wide" in name] if "decompress" in name else (4 if "wide" in name else 2)
+        valu = per["VALU"] / nhc
+        print(f"{short:44s} grid {grid:3d} x {block}: " + "  ".join(f"{c} {per[c] / nhc:7.1f}" for c in ("VALU", "SALU", "LDS", "VMEM", "branch", "s_waitcnt", "s_nop", "s_barrier"))
+              + f"  | per wavefront: VALU {valu / waves_per_hc:6.0f}  | VALU issue cycles per hypercube and SIMD (4 SIMDs share a hypercube's wavefronts): {valu * 4 / 4:6.0f}")
+        top = collections.Counter({op: n for (k, op), n in gx.PROFILE.items() if k == name})
+        print("    top: " + ", ".join(f"{op} {n / nhc:.0f}" for op, n in top.most_common(14)))
+
+
+if __name__ == "__main__":
+    main()
