@@ -287,6 +287,10 @@ class Wave:
         self.vgpr_written = {}
         self.sgpr_written = {}
         self.exec_written = -100
+        # s_waitcnt bookkeeping (check_waits): memory operations issued and not yet waited for, oldest first
+        self.vm_queue = []    # [set of destination VGPRs] per vector-memory operation (empty set: a store)
+        self.lgkm_queue = []  # [(kind, set of destination registers)]: kind "lds" (VGPRs), "ldsw" (an LDS store), "smem" (SGPRs, as -1 - n)
+        self.pending = {}     # register -> number of queued operations that will write it (VGPR n: n, SGPR n: -1 - n)
 
     # ---- operand access ---------------------------------------------------------------------------------------------------
     def rs32(self, tok: str) -> int:
@@ -1262,6 +1266,84 @@ def check_hazards(w, ins):
     w.clock = now + states
 
 
+# What a missing s_waitcnt would look like.  The interpreter completes every memory operation at once, so a missing wait cannot
+# change a result here -- instead the counters are kept as bookkeeping: every vector-memory operation joins the wavefront's vmcnt queue,
+# every LDS / scalar-memory operation its lgkmcnt queue, s_waitcnt retires what the counter value guarantees (gfx9: vector-memory
+# operations and LDS operations complete in issue order; scalar loads in any order, so with one queued only lgkmcnt(0) says anything),
+# and an instruction that reads or writes a register some queued load has yet to deliver, or a barrier crossed with this wavefront's
+# LDS stores still queued, is reported.  This is what stands behind the inline assembly's explicit waits (lds_append_complete).
+WAIT_LOG = []
+
+
+def _wait_info(ins):
+    """(vector registers touched, scalar registers touched (as -1 - n), what it queues: None | ("vm" | "lds" | "ldsw" | "smem", destination registers))"""
+    op, args = ins.op, ins.args
+    touched = set()
+    for tok in args:
+        for n in _regs_of(tok, "v"):
+            touched.add(n)
+        for n in _regs_of(tok, "s"):
+            touched.add(-1 - n)
+    queues = None
+    if op.startswith("global_load") or (op.startswith("global_atomic") and len(args) == 4):
+        queues = ("vm", set(_regs_of(args[0], "v")))
+    elif op.startswith(("global_store", "global_atomic")):
+        queues = ("vm", set())
+    elif op.startswith(("ds_read", "ds_bpermute")):
+        queues = ("lds", set(_regs_of(args[0], "v")))
+    elif op.startswith("ds_write"):
+        queues = ("ldsw", set())
+    elif op.startswith("s_load"):
+        queues = ("smem", {-1 - n for n in _regs_of(args[0], "s")})
+    return touched, queues
+
+
+def _retire(w, entry):
+    for r in entry:
+        c = w.pending.get(r, 0) - 1
+        if c <= 0:
+            w.pending.pop(r, None)
+        else:
+            w.pending[r] = c
+
+
+def check_waits(w, ins):
+    op = ins.op
+    if op == "s_waitcnt":
+        if "vmcnt" in ins.mods:
+            n = int(ins.mods["vmcnt"], 0)
+            while len(w.vm_queue) > n:
+                _retire(w, w.vm_queue.pop(0))
+        if "lgkmcnt" in ins.mods:
+            n = int(ins.mods["lgkmcnt"], 0)
+            if n == 0 or not any(k == "smem" for k, _ in w.lgkm_queue):
+                while len(w.lgkm_queue) > n:
+                    _retire(w, w.lgkm_queue.pop(0)[1])
+        return
+    if op == "s_barrier":
+        if any(k == "ldsw" for k, _ in w.lgkm_queue):
+            WAIT_LOG.append((ins.addr, ins.text, "s_barrier with LDS stores of this wavefront not waited for (lgkmcnt)"))
+        return
+    info = ins.mods.get("_wait")
+    if info is None:
+        info = ins.mods["_wait"] = _wait_info(ins)
+    touched, queues = info
+    if w.pending:
+        dst = queues[1] if queues else ()
+        for r in touched:
+            if r in w.pending and r not in dst:  # (a later load into the same register returns behind the earlier one: in order)
+                name = f"v{r}" if r >= 0 else f"s{-1 - r}"
+                WAIT_LOG.append((ins.addr, ins.text, f"{name} is the destination of a memory operation that has not been waited for"))
+    if queues:
+        kind, dst = queues
+        if kind == "vm":
+            w.vm_queue.append(dst)
+        else:
+            w.lgkm_queue.append((kind, dst))
+        for r in dst:
+            w.pending[r] = w.pending.get(r, 0) + 1
+
+
 class Kernel:
     def __init__(self, co: CodeObject, name: str):
         self.co, self.name = co, name
@@ -1366,6 +1448,7 @@ def run_grid(kernel: Kernel, grid: int, block: int, dynamic_lds: int, explicit_a
                     if trace is not None:
                         trace(w, ins)
                     check_hazards(w, ins)
+                    check_waits(w, ins)
                     if PROFILE is not None:
                         PROFILE[(kernel.name, ins.op)] += 1
                     try:

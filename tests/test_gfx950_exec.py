@@ -286,7 +286,38 @@ def test_lookback_timeout_path_of_the_code_object(tmp_path, monkeypatch):
     assert sum("compress_kernel_db" in n for n, *_ in b.launched) >= 2
 
 
+def test_waitcnt_checker_fires_on_what_it_is_meant_to_catch():
+    """the s_waitcnt bookkeeping of tests/gfx950_exec.py::check_waits on hand-made sequences: a loaded register used before the counter
+    says it has arrived, a scalar load consumed under lgkmcnt(1), a barrier crossed with LDS stores in flight -- reported; the
+    properly waited forms -- clean (in-order return: vmcnt(1) frees the older of two loads)"""
+    def run(lines):
+        w = gx.Wave(gx.Workgroup(0, 1, 64), 0, {}, 0)
+        before = len(gx.WAIT_LOG)
+        for k, text in enumerate(lines):
+            op, _, rest = text.partition(" ")
+            args, mods = gx._split_operands(rest)
+            gx.check_waits(w, gx.Ins(op, args, mods, 4 * k, 4, text))
+        found = gx.WAIT_LOG[before:]
+        del gx.WAIT_LOG[before:]
+        return found
+
+    load1, load2 = "global_load_dword v1, v2, s[0:1]", "global_load_dwordx4 v[4:7], v2, s[0:1] offset:16"
+    assert len(run([load1, "v_add_u32_e32 v3, v1, v1"])) == 1
+    assert run([load1, "s_waitcnt vmcnt(0)", "v_add_u32_e32 v3, v1, v1"]) == []
+    assert run([load1, load2, "s_waitcnt vmcnt(1)", "v_add_u32_e32 v3, v1, v1"]) == []           # the older load has returned
+    assert len(run([load1, load2, "s_waitcnt vmcnt(1)", "v_add_u32_e32 v3, v6, v1"])) == 1       # ... the younger one has not
+    assert len(run([load1, "v_mov_b32_e32 v1, 0"])) == 1                                          # overwriting a register a load will write
+    assert len(run(["ds_read_b32 v8, v9", "s_load_dword s4, s[0:1], 0x0", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v3, v8"])) == 1  # (scalar loads return in any order)
+    assert run(["ds_read_b32 v8, v9", "ds_read_b32 v10, v9 offset:4", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v3, v8"]) == []
+    assert len(run(["s_load_dwordx2 s[4:5], s[0:1], 0x8", "s_add_u32 s6, s4, 1"])) == 1
+    assert len(run(["ds_write_b32 v1, v2", "s_barrier"])) == 1                                    # what lds_append_complete() is there for
+    assert run(["ds_write_b32 v1, v2", "s_waitcnt lgkmcnt(0)", "s_barrier"]) == []
+
+
 def test_no_wait_state_hazard_in_any_executed_stream():
     """(last in this module) every instruction the tests above executed went through the hazard rules: nothing reported -- in
     particular not at the boundaries of the inline assembly, which the compiler's own hazard recogniser cannot see into"""
     assert gx.HAZARD_LOG == [], gx.HAZARD_LOG[:5]
+    # ... and through the s_waitcnt bookkeeping: no register used before its load was waited for, no barrier crossed with LDS stores
+    # in flight (the compaction's ds_write_b32 sit inside an asm statement: the compiler does not count them)
+    assert gx.WAIT_LOG == [], gx.WAIT_LOG[:5]
