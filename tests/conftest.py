@@ -14,13 +14,21 @@ def pytest_addoption(parser):
                      help="run the `-m gpu` tests' CODE on the CPU against the kernels' functional model (tests/wavesim): host tensors, "
                           "synchronous 'streams'; full-size and subprocess cases are skipped.  A rehearsal of the GPU suite in the GPU-less "
                           "authoring container -- it is not the GPU run and proves nothing about the hardware.")
+    parser.addoption("--rehearse-on-code-object", action="store_true", default=False,
+                     help="like --rehearse-on-model, but every kernel launch is executed from the BUILT gfx950 code objects by the instruction-level "
+                          "interpreter (tests/gfx950_exec.py); the full-size configurations are skipped (hours).  A one-off campaign "
+                          "(tools/README.md), not part of the CPU suite.")
 
 
 def pytest_configure(config):
+    if config.getoption("--rehearse-on-code-object"):
+        config.option.rehearse_on_model = True
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "hardware_only: a gpu test that cannot be rehearsed on the functional model (size, subprocess, real runtime)")
     if config.getoption("--rehearse-on-model"):
         _enter_rehearsal()
+    if config.getoption("--rehearse-on-code-object"):
+        _enter_code_object_rehearsal()
 
 
 def pytest_sessionstart(session):
@@ -66,9 +74,12 @@ def pytest_collection_modifyitems(config, items):
     if not config.getoption("--rehearse-on-model"):
         return
     skip = pytest.mark.skip(reason="hardware only: not part of the rehearsal on the functional model")
+    too_long = pytest.mark.skip(reason="full-size configuration / stress case: hours on the instruction-level interpreter")
     for item in items:
         if "hardware_only" in item.keywords:
             item.add_marker(skip)
+        elif config.getoption("--rehearse-on-code-object") and ("full_size" in item.name or "test_hip_stress" in item.nodeid):
+            item.add_marker(too_long)  # (the stress cases: tens of thousands of hypercubes)
 
 
 _rehearsal = contextlib.ExitStack()
@@ -98,6 +109,41 @@ def _enter_rehearsal():
     torch.cuda.Stream = _Stream
     torch.cuda.stream = lambda s: contextlib.nullcontext()
     torch.cuda.is_available = lambda: True
+
+
+def _enter_code_object_rehearsal():
+    """On top of the model rehearsal: every kernel launch of the model's host side runs as gfx950 code (tests/gfx950_exec.py)."""
+    import tempfile
+
+    from ndzip_amd import hip
+    from tests import gfx950_exec as gx
+    from tests.wavesim import build as simbuild
+
+    bridge = gx.Bridge(simbuild.build(), [hip.LIB_PATH, hip.STAGES_LIB_PATH], tempfile.mkdtemp(prefix="gfx950_rehearsal"))
+    _rehearsal.enter_context(bridge)
+    _code_object_bridge.append(bridge)
+
+
+_code_object_bridge = []
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    outcome = yield
+    if _code_object_bridge and outcome.excinfo is None:
+        b = _code_object_bridge[0]
+        if b.error is not None:  # (an interpreter error cannot cross the model's C frames: it is kept and the launch falls back)
+            err, b.error = b.error, None
+            raise err
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _code_object_bridge:  # one line per process (xdist worker) with what the interpreter did: tools/README.md sums them up
+        from tests import gfx950_exec as gx
+
+        b = _code_object_bridge[0]
+        with open(os.path.join(os.environ.get("CODE_OBJECT_REHEARSAL_STATS", "/tmp"), f"code_object_rehearsal.{os.getpid()}.txt"), "w") as f:
+            f.write(f"launches {b.total_launches} instructions {b.total_instructions} hazards {len(gx.HAZARD_LOG)} waits {len(gx.WAIT_LOG)}\n")
 
 
 @pytest.fixture(scope="session")

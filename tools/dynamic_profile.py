@@ -49,6 +49,7 @@ def main():
     want = oracle.compress(data)
     nhc = hip.num_hypercubes(shape)
     gx.PROFILE = collections.Counter()
+    gx.LDS_PROFILE = collections.defaultdict(lambda: [0, 0, 0, 0])
     bridge = gx.Bridge(simbuild.build(), [hip.LIB_PATH], tempfile.mkdtemp(prefix="gfx950_prof"))
     with bridge:
         got = sim.compress(data, cus=4, blocks_per_cu=2)
@@ -69,6 +70,12 @@ def main():
         valu = per["VALU"] / nhc
         print(f"{short:44s} grid {grid:3d} x {block}: " + "  ".join(f"{c} {per[c] / nhc:7.1f}" for c in ("VALU", "SALU", "LDS", "VMEM", "branch", "s_waitcnt", "s_nop", "s_barrier"))
               + f"  | per wavefront: VALU {valu / waves_per_hc:6.0f}  | VALU issue cycles per hypercube and SIMD (4 SIMDs share a hypercube's wavefronts): {valu * 4 / 4:6.0f}")
+        lds = [(op, r) for (k, op), r in gx.LDS_PROFILE.items() if k == name]
+        arr, ideal, busy = (sum(r[j] for _, r in lds) for j in (1, 2, 3))
+        floor = sum(r[0] * gx._LDS_RULES[op][2] for op, r in lds)
+        print(f"    LDS (the guide's lane groups and banks on the executed addresses): array cycles {arr / nhc:.0f} per hypercube, conflict-free {ideal / nhc:.0f}, "
+              f"extra {(arr - ideal) / max(arr, 1):.1%} [SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE]; pipe busy {busy / nhc:.0f}, {floor / nhc:.0f} without conflicts; "
+              + ", ".join(f"{op} {r[1] / max(r[2], 1):.2f}x" for op, r in sorted(lds, key=lambda kv: -(kv[1][1] - kv[1][2]))[:5]))
         top = collections.Counter({op: n for (k, op), n in gx.PROFILE.items() if k == name})
         print("    top: " + ", ".join(f"{op} {n / nhc:.0f}" for op, n in top.most_common(14)))
 
