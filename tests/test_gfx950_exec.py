@@ -87,9 +87,9 @@ def test_f32_3d_unpaired_tiles(bridge):
     assert any(n.endswith("Lb1ELb0EEEvPKNS_7word_ofIT_E4typeENS_9grid_geomEPjPS5_PyS9_jS9_jS9_j") for n in names), names
 
 
-@pytest.mark.parametrize("quantum,cus,resident", [(37, 8, 16), (700, 3, 3), (4000, 8, 16), (150, 2, 1)])
+@pytest.mark.parametrize("quantum,cus,resident", [(37, 8, 32), (700, 3, 3), (4000, 8, 32), (150, 2, 1)])
 def test_tickets_and_lookback_under_different_interleavings(bridge, quantum, cus, resident, monkeypatch):
-    """24 tiles over 16 workgroups in flight (sixteen ticket classes: the launcher's grid is what is resident, and the classes rely
+    """24 tiles over 16 (24) workgroups, all in flight (sixteen ticket classes: the launcher's grid is what is resident, and the classes rely
     on it), and over 6 / 4 workgroups of which only 3 / 1 are in flight at a time (one class = a single global order, which needs no
     co-residency at all).  The wavefronts in flight are interleaved `quantum` instructions at a time, so aggregates are published
     and windows are read in very different orders from case to case."""
@@ -101,7 +101,8 @@ def test_tickets_and_lookback_under_different_interleavings(bridge, quantum, cus
         got = sim.compress(data, cus=cus, blocks_per_cu=2)  # (the occupancy is cached per process: 2 workgroups per "CU" since the first launch)
     assert len(got) == len(want) and np.array_equal(got, want)
     (name, grid, block, _), = [l for l in bridge.launched if "compress_kernel" in l[0]]
-    assert grid == 2 * cus and block == 256
+    # (workgroups per "CU" = what the process's first launch cached: 2 in this module's order, 3 if another module's test ran first)
+    assert grid in (2 * cus, 3 * cus) and block == 256 and (grid >= 16) == (cus == 8)
 
 
 def test_device_wide_scan_stage(bridge):
