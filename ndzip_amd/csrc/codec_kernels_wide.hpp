@@ -366,10 +366,18 @@ NDZIP_DEV void decode_residuals(const char *region, uint32_t run_off, uint32_t *
     // inverse of coding<uint64_t>::transpose: one 32x32 transpose per lane -- the even lane then holds the HIGH dwords of the
     // pair's 32 values, the odd lane the LOW dwords -- and the pair swaps halves back (16 DPP moves)
     transpose32(w);
+    // even lane: value j = (own w[j], the odd lane's w[j]); odd lane: value 16 + j = (the even lane's w[16 + j], own w[16 + j]):
+    // swap and choice in one v_cndmask_b32_dpp per dword (gfx950_lds.hpp: pair_exchange_select4), two instructions per value where
+    // "select what to send, DPP move, two selects" took four
+    const uint32_t odd_flag = static_cast<uint32_t>(q & 1);
 #pragma unroll
-    for (int j = 0; j < vals; ++j) {
-        const uint32_t got = pair_swap(odd ? w[j] : w[vals + j]);  // the odd lane sends the low dwords of the even lane's values
-        r[j] = odd ? (static_cast<uint64_t>(got) << 32) | w[vals + j] : (static_cast<uint64_t>(w[j]) << 32) | got;
+    for (int j = 0; j < vals; j += 4) {
+        const uint32_t a[4] = {w[j], w[j + 1], w[j + 2], w[j + 3]};
+        const uint32_t b[4] = {w[vals + j], w[vals + j + 1], w[vals + j + 2], w[vals + j + 3]};
+        uint32_t lo[4], hi[4];
+        pair_exchange_select4(odd_flag, a, b, lo, hi);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[j + k] = (static_cast<uint64_t>(hi[k]) << 32) | lo[k];
     }
 }
 

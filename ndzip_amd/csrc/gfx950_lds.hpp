@@ -238,6 +238,30 @@ NDZIP_DEV void row_scan_step64(uint32_t (&lo)[8], uint32_t (&hi)[8]) {
 #undef NDZIP_ROWADD8
 #undef NDZIP_ROWADD1
 
+// Exchange between the two lanes of a pair (t, t ^ 1) fused with the choice of what to keep, for four word pairs (a[j], b[j]):
+//   lo[j] = odd lane ? own b[j] : the other lane's a[j]        hi[j] = odd lane ? the other lane's b[j] : own a[j]
+// as ONE v_cndmask_b32_dpp each (quad_perm [1,0,3,2] on the swapped operand) instead of a DPP move and a select: the compiler
+// folds a DPP move into src0 of a VOP2 instruction, but not across the select's operand order / inverted mask it would take here.
+// `odd_flag`: non-zero in odd lanes.  Every lane of the wavefront executes this (a DPP operand reads lanes that must be active).
+// Wait states: s_nop 1 in front (VALU write of a VGPR -> DPP read: 2); VCC is written by v_cmp (VALU) and read by v_cndmask as
+// its mask: no software wait state on gfx9.  VCC is clobbered.
+#define NDZIP_SWAPSEL(n) "v_cndmask_b32_dpp %[lo" #n "], %[a" #n "], %[b" #n "], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define NDZIP_SWAPSEL_HI(n) "v_cndmask_b32_dpp %[hi" #n "], %[b" #n "], %[a" #n "], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+NDZIP_DEV void pair_exchange_select4(uint32_t odd_flag, const uint32_t (&a)[4], const uint32_t (&b)[4], uint32_t (&lo)[4], uint32_t (&hi)[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_cmp_ne_u32_e32 vcc, 0, %[odd]\n\t"  // vcc = odd lanes: lo = vcc ? b : swap(a)
+                 NDZIP_SWAPSEL(0) NDZIP_SWAPSEL(1) NDZIP_SWAPSEL(2) NDZIP_SWAPSEL(3)
+                 "v_cmp_eq_u32_e32 vcc, 0, %[odd]\n\t"  // vcc = even lanes: hi = vcc ? a : swap(b)
+                 NDZIP_SWAPSEL_HI(0) NDZIP_SWAPSEL_HI(1) NDZIP_SWAPSEL_HI(2) NDZIP_SWAPSEL_HI(3)
+                 : [lo0] "=&v"(lo[0]), [lo1] "=&v"(lo[1]), [lo2] "=&v"(lo[2]), [lo3] "=&v"(lo[3]), [hi0] "=&v"(hi[0]), [hi1] "=&v"(hi[1]),
+                   [hi2] "=&v"(hi[2]), [hi3] "=&v"(hi[3])
+                 : [odd] "v"(odd_flag), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b0] "v"(b[0]), [b1] "v"(b[1]),
+                   [b2] "v"(b[2]), [b3] "v"(b[3])
+                 : "vcc");
+}
+#undef NDZIP_SWAPSEL_HI
+#undef NDZIP_SWAPSEL
+
 // The stores of lds_append_nonzero are invisible to the compiler's s_waitcnt bookkeeping (inline asm is opaque to it): the
 // workgroup barrier behind which other wavefronts read the compacted run must be preceded by this explicit wait.  (In the builds
 // looked at the compiler had an lgkmcnt(0) of its own in front of that barrier -- for the chunk head it stores itself -- but

@@ -122,6 +122,16 @@ NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
 
 NDZIP_DEV void lds_append_complete() {}
 
+// lo[j] = odd ? own b[j] : the pair lane's a[j];  hi[j] = odd ? the pair lane's b[j] : own a[j]   (product: v_cndmask_b32_dpp)
+NDZIP_DEV void pair_exchange_select4(uint32_t odd_flag, const uint32_t (&a)[4], const uint32_t (&b)[4], uint32_t (&lo)[4], uint32_t (&hi)[4]) {
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t other_a = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(a[j]), 0xb1, 0xf, 0xf, true));
+        const uint32_t other_b = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(b[j]), 0xb1, 0xf, 0xf, true));
+        lo[j] = odd_flag ? b[j] : other_a;
+        hi[j] = odd_flag ? other_b : a[j];
+    }
+}
+
 // v += row_shr:D(v) for eight 64-bit values as (lo, hi) pairs (product: v_add_co_u32_dpp + v_addc_co_u32_dpp in assembly)
 template<int D>
 NDZIP_DEV void row_scan_step64(uint32_t (&lo)[8], uint32_t (&hi)[8]) {
