@@ -208,13 +208,22 @@ struct coding<uint64_t> {
         return static_cast<uint32_t>(__builtin_popcount(head_hi) + __builtin_popcount(head_lo));
     }
     NDZIP_DEV static void transpose(const uint64_t (&r)[vals], int t, uint32_t (&planes)[planes_per_lane]) {
-        const bool odd = (t & 1) != 0;
+        // the even lane sends its low dwords, the odd lane its high ones: planes[j] (values 0..15 of the pair, the even lane's) =
+        // odd ? the even lane's low dword : own high dword; planes[16 + j] (the odd lane's values) = odd ? own low dword : the odd
+        // lane's high dword -- swap and choice in one v_cndmask_b32_dpp per dword (gfx950_lds.hpp: pair_exchange_select4)
+        const uint32_t odd_flag = static_cast<uint32_t>(t & 1);
 #pragma unroll
-        for (int j = 0; j < vals; ++j) {
-            const uint32_t hi = static_cast<uint32_t>(r[j] >> 32), lo = static_cast<uint32_t>(r[j]);
-            const uint32_t got = pair_swap(odd ? hi : lo);  // the even lane sends its low dwords, the odd lane its high ones
-            planes[j] = odd ? got : hi;                      // values 0..15 of the pair: the even lane's
-            planes[vals + j] = odd ? lo : got;               // values 16..31 of the pair: the odd lane's
+        for (int j = 0; j < vals; j += 4) {
+            const uint32_t hi[4] = {static_cast<uint32_t>(r[j] >> 32), static_cast<uint32_t>(r[j + 1] >> 32), static_cast<uint32_t>(r[j + 2] >> 32),
+                    static_cast<uint32_t>(r[j + 3] >> 32)};
+            const uint32_t lo[4] = {static_cast<uint32_t>(r[j]), static_cast<uint32_t>(r[j + 1]), static_cast<uint32_t>(r[j + 2]), static_cast<uint32_t>(r[j + 3])};
+            uint32_t own_half[4], other_half[4];
+            pair_exchange_select4(odd_flag, hi, lo, own_half, other_half);  // (lo_out = odd ? lo : swap(hi); hi_out = odd ? swap(lo) : hi)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                planes[j + k] = other_half[k];
+                planes[vals + j + k] = own_half[k];
+            }
         }
         transpose32(planes);
     }
