@@ -379,14 +379,13 @@ NDZIP_DEV uint32_t wave_sum(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_scan(v, 0)), 63));
 }
 
-template<typename W>
-NDZIP_DEV W wave_inclusive_scan_w(W v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const W o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    return v;
+// the same for the value type's word: 32 bits = the scan above; 64 bits = its twelve-instruction counterpart with the carry taken along
+// (gfx950_lds.hpp: wave_inclusive_scan64) -- rounds 1-3 ran six __shfl_up steps here (ds_bpermute_b32 pairs, compare, selects)
+NDZIP_DEV uint32_t wave_inclusive_scan_w(uint32_t v, int lane) { return wave_inclusive_scan(v, lane); }
+NDZIP_DEV uint64_t wave_inclusive_scan_w(uint64_t v, int /* lane */) {
+    uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
+    wave_inclusive_scan64(lo, hi);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -833,7 +832,7 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
     if constexpr (Dims == 1) {
 #pragma unroll
         for (int j = 1; j < 32; ++j) r[j] += r[j - 1];
-        const W incl = wave_inclusive_scan_w<W>(r[31], lane);
+        const W incl = wave_inclusive_scan_w(r[31], lane);
         W *xw = reinterpret_cast<W *>(xchg + 2);  // 2 words of W after the two uint32
         __syncthreads();                           // xchg[0..1] reads above are complete
         if (lane == 63) xw[wave] = incl;
@@ -844,7 +843,9 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
     } else if constexpr (Dims == 2) {
 #pragma unroll
         for (int j = 1; j < 32; ++j) r[j] += r[j - 1];
-        const W left = __shfl_up(r[31], 1, 64);
+        // (the left half row's total from lane t - 1: a DPP row shift -- an odd lane's predecessor is always in its own 16-lane row --
+        // where __shfl_up was a ds_bpermute_b32 round trip through the LDS crossbar)
+        const W left = group8_shift_up<1>(r[31], ~0u);
         if (t & 1) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) r[j] += left;

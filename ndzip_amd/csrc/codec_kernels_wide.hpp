@@ -427,7 +427,7 @@ NDZIP_DEV void inverse_transform(uint64_t (&r)[vals], uint64_t *__restrict__ out
     for (int j = 1; j < vals; ++j) r[j] += r[j - 1];  // x (1D: the work-item's 16 consecutive values)
     if constexpr (Dims == 1) {
         W *carries = reinterpret_cast<W *>(smem + D::carries_offset);
-        const W incl = wave_inclusive_scan_w<W>(r[vals - 1], lane);
+        const W incl = wave_inclusive_scan_w(r[vals - 1], lane);
         if (lane == 63) carries[wave] = incl;
         __syncthreads();
         W carry = incl - r[vals - 1];

@@ -238,6 +238,29 @@ NDZIP_DEV void row_scan_step64(uint32_t (&lo)[8], uint32_t (&hi)[8]) {
 #undef NDZIP_ROWADD8
 #undef NDZIP_ROWADD1
 
+// Inclusive prefix sum of ONE 64-bit value per lane over the 64 lanes of the wavefront, as (lo, hi): the six steps of the 32-bit
+// DPP scan (row_shr 1 / 2 / 4 / 8, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) with the carry taken along --
+// v_add_co_u32_dpp + v_addc_co_u32_dpp per step, twelve VALU instructions and no LDS traffic.  (__shfl_up on a 64-bit value is two
+// ds_bpermute_b32 plus a compare, two selects and a 64-bit add per step: six dependent LDS-crossbar round trips and ~50
+// instructions on the path of the 1D decoders' carry.)  Wait states: the DPP operand of a step was written by the step before --
+// add_co (lo), addc (hi), then s_nop 0 puts 2 wait states between each write and its DPP read; s_nop 1 in front for whatever the
+// compiler computed last.  Lanes of rows a row_mask disables are not written (their VCC bit is irrelevant: the addc is disabled too).
+#define NDZIP_SCAN64_STEP(ctrl) \
+    "v_add_co_u32_dpp %[lo], vcc, %[lo], %[lo] " ctrl "\n\tv_addc_co_u32_dpp %[hi], vcc, %[hi], %[hi], vcc " ctrl "\n\ts_nop 0\n\t"
+NDZIP_DEV void wave_inclusive_scan64(uint32_t &lo, uint32_t &hi) {
+    asm volatile("s_nop 1\n\t"
+                 NDZIP_SCAN64_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 NDZIP_SCAN64_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 NDZIP_SCAN64_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 NDZIP_SCAN64_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 NDZIP_SCAN64_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 NDZIP_SCAN64_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : [lo] "+v"(lo), [hi] "+v"(hi)
+                 :
+                 : "vcc");
+}
+#undef NDZIP_SCAN64_STEP
+
 // Exchange between the two lanes of a pair (t, t ^ 1) fused with the choice of what to keep, for four word pairs (a[j], b[j]):
 //   lo[j] = odd lane ? own b[j] : the other lane's a[j]        hi[j] = odd lane ? the other lane's b[j] : own a[j]
 // as ONE v_cndmask_b32_dpp each (quad_perm [1,0,3,2] on the swapped operand) instead of a DPP move and a select: the compiler

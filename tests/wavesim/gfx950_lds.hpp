@@ -122,6 +122,23 @@ NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
 
 NDZIP_DEV void lds_append_complete() {}
 
+// inclusive prefix sum of one 64-bit value per lane over the wavefront (product: six v_add_co_u32_dpp + v_addc_co_u32_dpp steps)
+NDZIP_DEV void wave_inclusive_scan64(uint32_t &lo, uint32_t &hi) {
+    const auto step = [&](int ctrl, int row_mask, bool bound) {
+        const uint32_t sl = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), ctrl, row_mask, 0xf, bound));
+        const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi), ctrl, row_mask, 0xf, bound));
+        const uint64_t r = ((static_cast<uint64_t>(hi) << 32) | lo) + ((static_cast<uint64_t>(sh) << 32) | sl);
+        lo = static_cast<uint32_t>(r);
+        hi = static_cast<uint32_t>(r >> 32);
+    };
+    step(0x111, 0xf, true);
+    step(0x112, 0xf, true);
+    step(0x114, 0xf, true);
+    step(0x118, 0xf, true);
+    step(0x142, 0xa, false);
+    step(0x143, 0xc, false);
+}
+
 // lo[j] = odd ? own b[j] : the pair lane's a[j];  hi[j] = odd ? the pair lane's b[j] : own a[j]   (product: v_cndmask_b32_dpp)
 NDZIP_DEV void pair_exchange_select4(uint32_t odd_flag, const uint32_t (&a)[4], const uint32_t (&b)[4], uint32_t (&lo)[4], uint32_t (&hi)[4]) {
     for (int j = 0; j < 4; ++j) {
