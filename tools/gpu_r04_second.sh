@@ -2,7 +2,8 @@
 # Round-4 second call (after tools/gpu_r04_first.sh has produced parity + bench + PMC): what explains the numbers.
 #   A/B of HEAD against the libraries of the end of round 3 and round 2 and against HEAD with plain-policy input loads (cfg 2, cfg 1,
 #   f64 2D / 3D compress + decompress), the workgroups-per-CU sweep, the phase timers of the f32 compress iteration, the PMC passes of
-#   cfg 3 and of the f64 3D decoder in both mappings, the two-process stress.  Variants are built on the CPU beforehand
+#   cfg 3 and of the f64 3D decoder in both mappings.  (The two-process stress is NOT part of this batch any more: it is the one
+#   workload that has hung a box -- round 1 -- and a hung box is a strike; tools/gpu_two_process_stress.sh runs it on its own, last.)  Variants are built on the CPU beforehand
 #   (tools/build_history_variant.sh r03 5bc12d1 ..., tools/build_variant.sh timing --lab ...).   usage: tools/gpu_r04_second.sh <tag>
 tag=${1:-r04b}
 mkdir -p gpurun_out
@@ -23,10 +24,3 @@ TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summa
 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_3d_decode_wide.txt --config 5
 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_3d_decode_128.txt --config 5 --f64-work-items 128
 cp gpurun_out/traffic.json profiles/traffic.json 2>/dev/null
-for i in 1 2 3 4 5 6; do
-  echo "== run $i" >> ${O}_two_process_stress.txt
-  HSA_ENABLE_IPC_MODE_LEGACY=0 CHECK_EACH=0 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-      --master-port $((29510 + i)) tools/sharded_stress.py 40 >> ${O}_two_process_stress.txt 2>&1
-  echo "exit $?" >> ${O}_two_process_stress.txt
-done
-tail -14 ${O}_two_process_stress.txt
