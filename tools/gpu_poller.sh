@@ -13,7 +13,7 @@ while true; do
   if [ ! -f $lib ] || [ -n "$(find ndzip_amd/csrc -newer $lib -type f \( -name '*.hip' -o -name '*.hpp' -o -name '*.inl' \) | head -1)" ]; then
     echo "$(date +%T) skip: library stale"; sleep 120; continue
   fi
-  /usr/local/graft/bin/gpurun --timeout 3000 -- "bash tools/gpu_r04_first.sh $tag" > /tmp/gpurun_$tag.log 2>&1
+  /usr/local/graft/bin/gpurun --timeout 3400 -- "bash tools/gpu_r04_first.sh $tag" > /tmp/gpurun_$tag.log 2>&1
   rc=$?
   echo "$(date +%T) rc=$rc $(git rev-parse --short HEAD)"
   if [ $rc -ne 2 ] && [ $rc -ne 3 ]; then echo "RAN at $(git rev-parse --short HEAD)"; exit 0; fi

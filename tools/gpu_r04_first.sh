@@ -13,5 +13,5 @@ TRAFFIC_KEY=float32-512x512x512 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_sum
 cp gpurun_out/traffic.json profiles/traffic.json 2>/dev/null
 timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
 cat ${O}_bench_n1.json; tail -5 ${O}_bench_n1.err
-(timeout 800 bash tools/bench_configs.sh 2>&1) > ${O}_configs.txt
+(timeout 700 bash tools/bench_configs.sh 2>&1) > ${O}_configs.txt
 cat ${O}_configs.txt
