@@ -79,7 +79,11 @@ NDZIP_HIP_API int ndzip_hip_compressor_create(
 
 /* cuda_compressor<T>::compress(in_device_data, data_size, out_device_stream, out_device_stream_length)
  * (include/ndzip/cuda.hh:10-23, src/ndzip/cuda_codec.inl:554-603).  Asynchronous on the handle's stream.
- * `d_stream` must hold ndzip_hip_compressed_length_bound words; `d_stream_length_words` may be NULL. */
+ * `d_stream` must hold ndzip_hip_compressed_length_bound words; `d_stream_length_words` may be NULL.
+ * Pure stream work: one kernel (two with a border), no allocation, no host synchronisation and no per-call state on the host
+ * (what one launch hands to the next on the handle's scratch -- ticket counters, the tile descriptors' epoch -- is kept and
+ * advanced on the device).  A call may therefore be recorded into a hipGraph and replayed on new data in the same buffers
+ * (tests/test_hip_graph.py); the same holds for the decompress entry points, which keep no state at all. */
 NDZIP_HIP_API int ndzip_hip_compressor_compress(ndzip_hip_compressor *c, const void *d_in, int dims, const uint32_t *extent,
         void *d_stream, uint32_t *d_stream_length_words);
 

@@ -156,7 +156,6 @@ struct ndzip_hip_compressor {
     int device;          // the device the handle was created on (and launches on)
     int max_blocks_per_cu;  // 0 = full persistent grid; set to 1 for the relaunch after a look-back time-out (host-pointer paths)
     size_t desc_count;   // entries of `desc`
-    uint32_t epoch;      // launches on `desc` so far (descriptor epoch, codec_launch.inl)
 };
 
 struct ndzip_hip_decompressor {
@@ -218,13 +217,16 @@ int ndzip_hip_compressor_create(int dtype, int dims, uint32_t max_num_hypercubes
     if (!valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "Invalid dimensionality");  // common.hh:642
     int cus = 0, device = 0;
     if (int s = ensure_device(&cus, &device)) return s;
-    auto *c = new ndzip_hip_compressor{dtype, dims, max_num_hypercubes, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, cus, device, 0, 0, 0};
+    auto *c = new ndzip_hip_compressor{dtype, dims, max_num_hypercubes, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, cus, device, 0, 0};
     const uint32_t tiles = dtype == NDZIP_HIP_F32 ? compress_num_tiles<float>(dims, max_num_hypercubes)
                                                   : compress_num_tiles<double>(dims, max_num_hypercubes);
     c->desc_count = static_cast<size_t>(tiles) + scratch_extra_descs;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->desc), c->desc_count * sizeof(tile_desc));
-    // zeroed once: ticket counters start at 0 (the kernel restores that on its way out), descriptors carry an epoch
+    // zeroed once: ticket counters start at 0 (the kernel restores that on its way out), descriptors carry the launch epoch, which
+    // lives in the scratch and is advanced by the kernels themselves -- a compress call has no per-launch state on the host and can
+    // be recorded into a hipGraph
     if (e == hipSuccess) e = hipMemsetAsync(c->desc, 0, c->desc_count * sizeof(tile_desc), c->stream);
+    if (e == hipSuccess) e = init_scratch_epoch(c->desc, tiles, c->stream);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->err), sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(c->err, 0, sizeof(uint32_t), c->stream);
     if (e != hipSuccess) {
@@ -255,11 +257,6 @@ static int compress_common(ndzip_hip_compressor *c, const void *d_in, int dims, 
     a.header = d_header;
     a.body = d_body;
     a.desc = c->desc;
-    if (++c->epoch >= (1u << 30)) {  // the epoch field of a descriptor is 30 bits: start over on a clean scratch
-        HIP_TRY(hipMemsetAsync(c->desc, 0, c->desc_count * sizeof(tile_desc), c->stream));
-        c->epoch = 1;
-    }
-    a.epoch = c->epoch;
     a.out_len = d_len;
     a.len_extra = len_extra;
     a.err = c->err;

@@ -13,18 +13,27 @@ namespace ndzip_hip {
 using tile_desc = unsigned long long;
 
 // Scratch in front of the descriptors: 16 experiment counters, then one ticket counter per class, each in its own 128-byte
-// line, then the 'workgroups done' line (see release_tickets in codec_launch.inl).  Sizes in tile_desc units.
+// line, then the 'workgroups done' line (see release_tickets in codec_launch.inl), then the line of the launch epoch.  Sizes in
+// tile_desc units.
 constexpr unsigned ticket_classes = 16;       // ticket counters a launch uses (1 when the grid is smaller than that)
 constexpr unsigned ticket_stride_words = 32;  // uint32 words between the counters of consecutive classes
-constexpr unsigned scratch_extra_descs = 16 + (ticket_classes + 1) * ticket_stride_words / 2;
+constexpr unsigned scratch_extra_descs = 16 + (ticket_classes + 2) * ticket_stride_words / 2;
+// The launch epoch lives in the scratch, not in a kernel argument: every workgroup reads it on its way in, the last one to leave
+// writes the next one (release_tickets).  A launch therefore carries NO per-launch state from the host -- a compress call recorded
+// into a hipGraph replays correctly (with the epoch as an argument every replay would run under the recorded epoch, find the previous
+// replay's descriptors "published" and hand their stale lengths to the look-back: a silently wrong stream).
+// uint32 index from the first ticket counter; [epoch_word + 1] = number of descriptors behind the scratch (what the last workgroup
+// clears when the 30-bit epoch starts over).  The owner of the scratch sets both once (epoch 1).
+constexpr unsigned epoch_word = (ticket_classes + 1) * ticket_stride_words;
+constexpr unsigned epoch_limit = 1u << 30;
 
 struct compress_args {
     const void *in;        // device, value_type[num_elements]
     grid_geom gg;
     uint32_t *header;      // device, NHC uint32 entries (+1 pad entry for 64-bit streams with odd NHC)
     void *body;            // device, first body word (= stream + header words for a contiguous stream)
-    tile_desc *desc;       // device scratch, >= num_tiles + scratch_extra_descs entries, zeroed ONCE by its owner
-    uint32_t epoch;        // launch counter of that scratch, 1 .. 2^30-1, different for every launch on it
+    tile_desc *desc;       // device scratch, >= num_tiles + scratch_extra_descs entries, zeroed ONCE by its owner, who also sets the
+                           // epoch line (init_scratch_epoch): the kernels advance the epoch themselves
     uint32_t *out_len;     // device scalar or nullptr
     uint32_t len_extra;    // header words + border words, added to the body length for *out_len
     uint32_t *err;         // device error word (sticky)
@@ -61,6 +70,15 @@ uint32_t compress_num_tiles(int dims, uint32_t nhc);
 template<typename T>
 hipError_t launch_compress(int dims, const compress_args &a);
 
+// once, behind the zeroing of a scratch (stream-ordered): epoch 1, `desc_count` descriptors
+inline hipError_t init_scratch_epoch(tile_desc *scratch, uint32_t desc_count, hipStream_t stream) {
+    const uint32_t first_epoch = 1;
+    uint32_t *line = reinterpret_cast<uint32_t *>(scratch + 16) + epoch_word;
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(line), static_cast<int>(first_epoch), 1, stream);
+    if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(line + 1), static_cast<int>(desc_count), 1, stream);
+    return e;
+}
+
 template<typename T>
 hipError_t launch_decompress(int dims, const decompress_args &a);
 
@@ -79,7 +97,7 @@ enum debug_stage : int {
     debug_lookback_scan = 7,      // in: n uint32 tile lengths           -> out: their n exclusive prefix sums, out[n] = the total,
                                   //     out[n + 1] = the error word; `hc` = workgroups of the persistent grid (0: as many as the
                                   //     production launch would use).  The production ticket / publish / look-back / release
-                                  //     functions on their own, two launches on one scratch (epoch 1 and 2): the device-wide
+                                  //     functions on their own, two launches on one scratch (the kernel's own epochs 1 and 2): the device-wide
                                   //     scan at tile counts no array that fits a test can reach
 };
 

@@ -41,7 +41,8 @@ struct tile_cfg {
     static constexpr uint32_t smem_bytes = K * cube_stride + L::zero_bytes + K * xchg_bytes + 32;
 };
 
-// Descriptor = (status << 32) | value with status = (epoch << 2) | state.  The epoch is a per-handle launch counter: a
+// Descriptor = (status << 32) | value with status = (epoch << 2) | state.  The epoch is a per-scratch launch counter (kept IN the
+// scratch and advanced by the kernel itself, codec_launch.hpp: epoch_word): a
 // descriptor left behind by an earlier launch has another epoch and reads as "not published", so the scratch needs no
 // clearing between launches (a 130 KiB memset node in front of every compress call cost ~4 us of a 200 us launch, and
 // 10 % of a 16 Mi-element one).  States: 0 unpublished, 1 aggregate, 2 inclusive prefix, 3 lane outside the window.
@@ -107,7 +108,12 @@ NDZIP_DEV uint32_t tile_of_ticket(uint32_t ticket, uint32_t cls, uint32_t num_cl
 NDZIP_DEV void store_stream_length(uint32_t *out_len, uint32_t words) {
     if (out_len) exchange_performed(out_len, words);
 }
-NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid, uint32_t *err, uint32_t *out_len) {
+// The launch's epoch: one agent-scope load per work-item on the way in (the word was written by the previous launch's last workgroup,
+// a kernel boundary ago), handed to the compiler as a scalar.
+NDZIP_DEV uint32_t launch_epoch(const uint32_t *tickets) {
+    return static_cast<uint32_t>(wave_uniform(static_cast<int>(__hip_atomic_load(tickets + epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+}
+NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid, uint32_t *err, uint32_t *out_len, desc_ref desc) {
     if (tid != 0) return;
     uint32_t *done = tickets + ticket_classes * ticket_stride_words;
     wait_for_own_memory_operations();
@@ -115,6 +121,17 @@ NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid,
         for (uint32_t c = 0; c < num_classes; ++c) tickets[c * ticket_stride_words] = 0;
         *done = 0;
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) store_stream_length(out_len, 0u);
+        // Every other workgroup has left: nobody reads the epoch or a descriptor of this launch any more.  The next launch on this
+        // scratch runs under epoch + 1; when the 30-bit field starts over, a descriptor an old launch left behind could carry the
+        // new epoch again, so the scratch is wiped first (once in 2^30 launches; by this one work-item, with the descriptors' own
+        // write-through stores).
+        uint32_t next = desc.epoch + 1;
+        if (next >= epoch_limit) {
+            const uint32_t count = tickets[epoch_word + 1];
+            for (uint32_t i = 0; i < count; ++i) desc_store(desc.p + i, 0);
+            next = 1;
+        }
+        __hip_atomic_store(tickets + epoch_word, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -348,8 +365,8 @@ template<typename T, int Dims, bool Aligned, bool Paired = false>
 __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (db_cfg<T, Dims, Paired>::min_waves_per_simd))
 compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
         typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
-        uint32_t *out_len, uint32_t len_extra, uint32_t *err, const uint32_t epoch) {
-    const desc_ref desc{desc_base, epoch};
+        uint32_t *out_len, uint32_t len_extra, uint32_t *err) {
+    const desc_ref desc{desc_base, launch_epoch(tickets)};
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -551,7 +568,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     }
     // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
     // visible); the descriptors need no clearing (epoch).
-    release_tickets(tickets, num_classes, tid, err, out_len);
+    release_tickets(tickets, num_classes, tid, err, out_len, desc);
 }
 
 // ---- the register-buffered deferred-write-out pipeline with 256 work-items per hypercube ("wide" mapping) ---------
@@ -571,9 +588,8 @@ struct wide_cfg {
 template<typename W, int Dims, bool Aligned>
 __global__ void __launch_bounds__((wide_cfg<W, Dims>::threads), (wide_cfg<W, Dims>::min_waves_per_simd))
 compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header, W *__restrict__ body,
-        tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes, uint32_t *out_len, uint32_t len_extra, uint32_t *err,
-        const uint32_t epoch) {
-    const desc_ref desc{desc_base, epoch};
+        tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes, uint32_t *out_len, uint32_t len_extra, uint32_t *err) {
+    const desc_ref desc{desc_base, launch_epoch(tickets)};
     using C = wide_cfg<W, Dims>;
     using L = wide::layout<W>;
     using E = wide::coding<W>;
@@ -697,7 +713,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
             }
         }
     }
-    release_tickets(tickets, num_classes, tid, err, out_len);
+    release_tickets(tickets, num_classes, tid, err, out_len, desc);
 }
 
 template<typename T, int Dims, bool Aligned>
@@ -1023,8 +1039,8 @@ __global__ void debug_wave_scan_kernel(const uint32_t *in, uint32_t *out, uint32
 // (Reference counterpart of what this checks: hierarchical_inclusive_scan at 2^24 elements, src/test/cuda_bits_test.cu:94-114.)
 __global__ void __launch_bounds__(64)
 debug_lookback_kernel(const uint32_t *__restrict__ lengths, uint32_t *__restrict__ exclusive, uint32_t ntiles, tile_desc *desc_base,
-        uint32_t *tickets, const uint32_t num_classes, uint32_t *total, uint32_t *err, const uint32_t epoch) {
-    const desc_ref desc{desc_base, epoch};
+        uint32_t *tickets, const uint32_t num_classes, uint32_t *total, uint32_t *err) {
+    const desc_ref desc{desc_base, launch_epoch(tickets)};
     __shared__ uint32_t slot[2];
     const int lane = static_cast<int>(threadIdx.x);
     const uint32_t cls = blockIdx.x % num_classes;
@@ -1063,7 +1079,7 @@ debug_lookback_kernel(const uint32_t *__restrict__ lengths, uint32_t *__restrict
         prev_aggregate = aggregate;
         tile = next_tile;
     }
-    release_tickets(tickets, num_classes, lane, err, total);
+    release_tickets(tickets, num_classes, lane, err, total, desc);
 }
 
 #endif  // NDZIP_STAGE_KERNELS
@@ -1103,8 +1119,9 @@ struct occupancy_cache {
 };
 
 // Scratch layout (fixed, whatever the extent): [16 x u64 reserved (lab builds: phase counters)][ticket counters, one per 128 B][1 line:
-// workgroups done][descriptors].  Nothing is cleared per launch: descriptors carry the launch epoch, the kernel zeroes the
-// ticket counters on its way out (the owner of the scratch zeroes everything once).
+// workgroups done][1 line: launch epoch, descriptor count][descriptors].  Nothing is cleared per launch and nothing about a launch
+// comes from the host: descriptors carry the launch epoch, which the kernel reads from the scratch and advances on its way out,
+// where it also zeroes the ticket counters (the owner of the scratch zeroes everything once and sets epoch 1: init_scratch_epoch).
 template<typename Kernel, typename W>
 hipError_t launch_persistent(Kernel kernel, int threads, uint32_t smem_bytes, int blocks_per_cu, uint32_t ntiles, const compress_args &a) {
     if (a.max_blocks_per_cu > 0 && blocks_per_cu > a.max_blocks_per_cu) blocks_per_cu = a.max_blocks_per_cu;
@@ -1114,7 +1131,7 @@ hipError_t launch_persistent(Kernel kernel, int threads, uint32_t smem_bytes, in
     const uint32_t num_classes = grid < ticket_classes ? 1u : ticket_classes;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem_bytes, a.stream, static_cast<const W *>(a.in), a.gg, a.header,
             static_cast<W *>(a.body), a.desc + scratch_extra_descs, reinterpret_cast<uint32_t *>(a.desc + 16), num_classes, a.out_len,
-            a.len_extra, a.err, a.epoch);
+            a.len_extra, a.err);
     return hipGetLastError();
 }
 
@@ -1254,9 +1271,10 @@ hipError_t launch_debug_stage<T_>(int stage, int dims, const grid_geom &gg, uint
         e = hipMemsetAsync(scratch, 0, entries * sizeof(tile_desc), stream);
         uint32_t *o = static_cast<uint32_t *>(out);
         if (e == hipSuccess) e = hipMemsetAsync(o + n, 0, 2 * sizeof(uint32_t), stream);
-        for (uint32_t epoch = 1; epoch <= 2 && e == hipSuccess; ++epoch) {
+        if (e == hipSuccess) e = init_scratch_epoch(scratch, n, stream);
+        for (int launch = 0; launch < 2 && e == hipSuccess; ++launch) {  // (the second one runs under the epoch the first one left)
             hipLaunchKernelGGL(debug_lookback_kernel, dim3(grid), dim3(64), 0, stream, static_cast<const uint32_t *>(in), o, n,
-                    scratch + scratch_extra_descs, reinterpret_cast<uint32_t *>(scratch + 16), num_classes, o + n, o + n + 1, epoch);
+                    scratch + scratch_extra_descs, reinterpret_cast<uint32_t *>(scratch + 16), num_classes, o + n, o + n + 1);
             e = hipGetLastError();
         }
         const hipError_t s = hipStreamSynchronize(stream);

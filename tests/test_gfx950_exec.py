@@ -84,7 +84,7 @@ def test_f64_decoder_with_128_work_items(bridge):
 def test_f32_3d_unpaired_tiles(bridge):
     """an odd hypercube count along x: compress_kernel_db<float, 3, true, false>"""
     names = _roundtrip(bridge, _mixed((16, 32, 48), np.float32, 41))
-    assert any(n.endswith("Lb1ELb0EEEvPKNS_7word_ofIT_E4typeENS_9grid_geomEPjPS5_PyS9_jS9_jS9_j") for n in names), names
+    assert any(n.endswith("Lb1ELb0EEEvPKNS_7word_ofIT_E4typeENS_9grid_geomEPjPS5_PyS9_jS9_jS9_") for n in names), names
 
 
 @pytest.mark.parametrize("quantum,cus,resident", [(37, 8, 32), (700, 3, 3), (4000, 8, 32), (150, 2, 1)])
@@ -212,6 +212,17 @@ def _codec_cases():
         cases.append((f"corrupt-header-{profile_id(p)}", ct.test_corrupt_header_entries_are_contained, (p,)))
         cases.append((f"zero-hypercubes-{profile_id(p)}", ct.test_zero_hypercubes, (p, 1)))
     return cases
+
+
+@pytest.mark.parametrize("dtype,shapes", [(np.float32, [(16 * 3, 16 * 2, 16 * 2), (16 * 1, 16 * 2, 16 * 2)]), (np.float64, [(64 * 2, 64 * 2), (64 * 1, 64 * 1)])])
+def test_launch_epoch_of_the_code_object(bridge, dtype, shapes):
+    """tests/test_wavesim_codec.py::test_launch_epoch_lives_in_the_scratch_and_starts_over on the interpreted code object: the epoch
+    load on the way in, the last workgroup's store of the next one, the wipe of the descriptors when the 30-bit field starts over."""
+    from tests import test_wavesim_codec as ct
+
+    with bridge:
+        ct.test_launch_epoch_lives_in_the_scratch_and_starts_over(dtype, shapes)
+    assert sum("compress_kernel" in n for n, *_ in bridge.launched) == 7, bridge.launched
 
 
 @pytest.mark.parametrize("case", _codec_cases(), ids=lambda c: c[0])

@@ -196,6 +196,40 @@ def test_host_pointer_offloader_and_pipelined_offloader(profile):
         po.close()
 
 
+@pytest.mark.parametrize("dtype,shapes", [(np.float32, [(16 * 5, 16 * 2, 16 * 4), (16 * 2, 16 * 2, 16 * 2), (16 * 5, 16 * 2, 16 * 4)]),
+                                          (np.float64, [(64 * 3, 64 * 2), (64 * 1, 64 * 2), (64 * 3, 64 * 2)])])
+def test_launch_epoch_lives_in_the_scratch_and_starts_over(dtype, shapes):
+    """A compress launch takes nothing per-launch from the host: the descriptor epoch is read from the scratch and advanced by the
+    last workgroup to leave (what lets a recorded launch be replayed from a hipGraph).  Here a fresh handle's epoch word is set two
+    launches below the end of the 30-bit field and the handle is used seven times, larger and smaller extents in turn: the
+    launch that ends on epoch 2^30 - 1 wipes the descriptors and hands epoch 1 to the next one; every stream equals the oracle's."""
+    with sim.active(cus=3, blocks_per_cu=2):
+        comp = hip.make_hip_compressor(dtype, hip.CompressorRequirements(*shapes))
+        # (white box, model only -- its "device memory" is the heap: the handle's scratch pointer sits behind {int, int, uint32, stream},
+        # the epoch word 16 reserved descriptors + (16 ticket lines + the 'done' line) x 128 bytes into the scratch)
+        import ctypes
+
+        scratch = ctypes.c_uint64.from_address(comp._h.value + 24).value
+        epoch_word = ctypes.c_uint32.from_address(scratch + 16 * 8 + 17 * 128)
+        assert epoch_word.value == 1  # (a fresh handle)
+        epoch_word.value = (1 << 30) - 2
+        expected = [(1 << 30) - 2, (1 << 30) - 1, 1, 2, 3, 4, 5, 6]
+        try:
+            for launch in range(7):
+                assert epoch_word.value == expected[launch], (launch, epoch_word.value)
+                shape = shapes[launch % len(shapes)]
+                data = synth_numpy(shape, dtype, seed=40 + launch, noise_mask=0xFFFF if launch % 2 else 0xFF)
+                want = oracle.compress(data)
+                out = np.zeros(hip.compressed_length_bound(dtype, shape), dtype=want.dtype)
+                length = np.zeros(1, dtype=np.uint32)
+                comp.compress(data.ctypes.data, shape, out.ctypes.data, length.ctypes.data)
+                comp.check()
+                assert int(length[0]) == len(want) and np.array_equal(out[: len(want)], want), f"launch {launch}"
+            assert epoch_word.value == expected[7]
+        finally:
+            comp.close()
+
+
 def test_lookback_timeout_stays_in_bounds_and_is_reported():
     """A look-back that gives up (library variant with a spin limit of 0: any wait for a predecessor is a timeout) after a
     LARGER earlier launch on the same handle, whose descriptors are still in the scratch with another epoch: the partial

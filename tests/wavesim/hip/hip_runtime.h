@@ -267,6 +267,11 @@ inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
     memset(d, v, n);
     return hipSuccess;
 }
+typedef void *hipDeviceptr_t;
+inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t) {
+    for (size_t i = 0; i < count; ++i) static_cast<int *>(d)[i] = v;
+    return hipSuccess;
+}
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
     *s = nullptr;
