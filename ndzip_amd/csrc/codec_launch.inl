@@ -109,10 +109,13 @@ NDZIP_DEV void store_stream_length(uint32_t *out_len, uint32_t words) {
     if (out_len) exchange_performed(out_len, words);
 }
 // The launch's epoch: one agent-scope load per work-item on the way in (the word was written by the previous launch's last workgroup,
-// a kernel boundary ago), handed to the compiler as a scalar.
-NDZIP_DEV uint32_t launch_epoch(const uint32_t *tickets) {
-    return static_cast<uint32_t>(wave_uniform(static_cast<int>(__hip_atomic_load(tickets + epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+// a kernel boundary ago).  In two halves so that the load's round trip -- a cold line: it comes from memory -- is not waited for in
+// front of the first ticket: issued first of all, turned into a scalar (v_readfirstlane, i.e. the s_waitcnt) only behind the first
+// barrier, by which time wavefront 0 has had its ticket back (loads and atomics return in order) and the others have been waiting.
+NDZIP_DEV uint32_t launch_epoch_load(const uint32_t *tickets) {
+    return __hip_atomic_load(tickets + epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+NDZIP_DEV uint32_t launch_epoch(uint32_t loaded) { return static_cast<uint32_t>(wave_uniform(static_cast<int>(loaded))); }
 NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid, uint32_t *err, uint32_t *out_len, desc_ref desc) {
     if (tid != 0) return;
     uint32_t *done = tickets + ticket_classes * ticket_stride_words;
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__((tile_cfg<T, Dims>::threads), (db_cfg<T, Dims,
 compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header,
         typename word_of<T>::type *__restrict__ body, tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes,
         uint32_t *out_len, uint32_t len_extra, uint32_t *err) {
-    const desc_ref desc{desc_base, launch_epoch(tickets)};
+    const uint32_t epoch_loaded = launch_epoch_load(tickets);
     using C = tile_cfg<T, Dims>;
     using W = typename C::W;
     using L = typename C::L;
@@ -405,6 +408,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
     if (tid == 0) misc[NW + 2] = first_ticket;
     __syncthreads();
+    const desc_ref desc{desc_base, launch_epoch(epoch_loaded)};
     // (tickets are the same in every lane: as scalars, so that the tile's origin -- two magic-number divisions and 64-bit
     // multiply-adds -- is computed once on the scalar unit, not per lane)
     uint32_t tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 2]))), cls, num_classes);
@@ -589,7 +593,7 @@ template<typename W, int Dims, bool Aligned>
 __global__ void __launch_bounds__((wide_cfg<W, Dims>::threads), (wide_cfg<W, Dims>::min_waves_per_simd))
 compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__restrict__ header, W *__restrict__ body,
         tile_desc *desc_base, uint32_t *tickets, const uint32_t num_classes, uint32_t *out_len, uint32_t len_extra, uint32_t *err) {
-    const desc_ref desc{desc_base, launch_epoch(tickets)};
+    const uint32_t epoch_loaded = launch_epoch_load(tickets);
     using C = wide_cfg<W, Dims>;
     using L = wide::layout<W>;
     using E = wide::coding<W>;
@@ -614,6 +618,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;
     if (tid == 0) misc[NW + 2] = first_ticket;
     __syncthreads();
+    const desc_ref desc{desc_base, launch_epoch(epoch_loaded)};
     uint32_t tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW + 2]))), cls, num_classes);
 
     wide::input_regs<W> pre;
@@ -1040,13 +1045,14 @@ __global__ void debug_wave_scan_kernel(const uint32_t *in, uint32_t *out, uint32
 __global__ void __launch_bounds__(64)
 debug_lookback_kernel(const uint32_t *__restrict__ lengths, uint32_t *__restrict__ exclusive, uint32_t ntiles, tile_desc *desc_base,
         uint32_t *tickets, const uint32_t num_classes, uint32_t *total, uint32_t *err) {
-    const desc_ref desc{desc_base, launch_epoch(tickets)};
+    const uint32_t epoch_loaded = launch_epoch_load(tickets);
     __shared__ uint32_t slot[2];
     const int lane = static_cast<int>(threadIdx.x);
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
     if (lane == 0) slot[0] = atomicAdd(ticket_counter, 1u);
     __syncthreads();
+    const desc_ref desc{desc_base, launch_epoch(epoch_loaded)};
     uint32_t tile = tile_of_ticket(static_cast<uint32_t>(wave_uniform(static_cast<int>(slot[0]))), cls, num_classes);
     bool have_prev = false;
     uint32_t prev_tile = 0, prev_aggregate = 0;
