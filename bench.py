@@ -230,7 +230,7 @@ def cpu_port_openmp(host_grid, cores, budget_s):
     path = os.path.join(shm, f"ndzip_bench_grid_{os.getpid()}.npy")
     np.save(path, host_grid)
     try:
-        # close binding on physical cores was the stable setting on the 2 x 64-core host (tools/cpu_env_probe.sh)
+        # close binding on physical cores was the stable setting on the 2 x 64-core host (round-1 measurement, profiles/README.md)
         env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
         env.pop("OMP_WAIT_POLICY", None)
         r = subprocess.run([sys.executable, "-m", "oracle.timing", path, str(cores), str(budget_s)], capture_output=True, text=True, cwd=ROOT,

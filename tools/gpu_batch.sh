@@ -1,0 +1,106 @@
+#!/bin/bash
+# THE GPU entry script of this repository (every other tools/gpu_* / _call1.sh of rounds 1-4 is folded into it).
+#
+#   tools/gpu_batch.sh first   <tag>   ON THE BOX, first call of a round: smoke -> whole -m gpu suite -> PMC passes (traffic.json, made BEFORE
+#                                      the bench line so that the line can carry roofline.traffic) -> bench.py (the driver's command) ->
+#                                      every BASELINE config + bookends + the f64 decoder A/B.       (worst case ~50 min, usually ~20)
+#   tools/gpu_batch.sh explain <tag>   ON THE BOX, second call: what explains the numbers -- A/B against the history / lab variants built on the
+#                                      CPU beforehand (tools/build_variant.sh, tools/build_history_variant.sh), workgroups-per-CU sweep, phase
+#                                      timers of the f32 compress iteration, PMC passes of cfg 3 and of both f64 3D decoders.
+#   tools/gpu_batch.sh stress  <tag>   ON THE BOX, own call, LAST: two processes on one GPU (the only workload that ever hung a box: round 1).
+#                                      Short timeouts, synchronised form first, stops at the first failure (a hung box is a strike).
+#   tools/gpu_batch.sh poll    <tag> [interval_s] [stage]
+#                                      HERE, in the background: every interval try ONE `gpurun -- tools/gpu_batch.sh <stage> <tag>`; a refused
+#                                      call costs nothing. Skipped while product sources have uncommitted edits or the library is stale, so the
+#                                      snapshot that reaches the box is always a committed, built state. Ends after the first call that ran.
+#   tools/gpu_batch.sh collect <tag> [name]
+#                                      HERE, after a call: copy what the judge should see from gpurun_out/<tag>_* to profiles/<name>_* (+
+#                                      traffic.json).  Do NOT touch ndzip_amd/csrc or build.FLAGS afterwards: traffic.json is keyed on
+#                                      kernels_fingerprint() and bench.py refuses counters of another build.
+# Every on-box step has its own timeout and writes its own file under gpurun_out/<tag>_* as soon as it ends.
+stage=${1:?stage: first | explain | stress | poll | collect}; tag=${2:?tag}
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+O=gpurun_out/$tag
+
+frac_line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('compress_ms', d['roofline']['launch_ms'], 'frac', d['roofline']['frac'])"; }
+
+case $stage in
+first)
+  rocminfo | grep -E "gfx|Compute Unit" | head -4 > ${O}_rocminfo.txt
+  (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -8) > ${O}_smoke.txt
+  cat ${O}_smoke.txt
+  (timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider --timeout 180 2>&1 | tail -120) > ${O}_gputest.txt
+  tail -30 ${O}_gputest.txt
+  TRAFFIC_KEY=float32-512x512x512 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary.txt
+  cp gpurun_out/traffic.json profiles/traffic.json 2>/dev/null
+  timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
+  cat ${O}_bench_n1.json; tail -5 ${O}_bench_n1.err
+  (timeout 700 bash tools/bench_configs.sh 2>&1) > ${O}_configs.txt
+  cat ${O}_configs.txt
+  ;;
+explain)
+  # variants present in ndzip_amd/_variants/ decide the A/B legs:
+  #   r04 / r03 / r02 = the library at the end of that round; plainloads = HEAD without the nt input loads; plain = HEAD without inline asm
+  #   lookahead / k1 = the two lab experiments of DESIGN section 5 (look-back window prefetch; 128-work-item f32 tile at 8 workgroups per CU)
+  V="main"; for v in r04 r03 r02 plainloads plain lookahead k1; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
+  (timeout 700 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt; cat ${O}_ab_variants.txt
+  (timeout 400 bash tools/ab.sh "$V" --config 1 2>&1) > ${O}_ab_variants_cfg1.txt
+  for w in 0 3 2 1; do echo -n "workgroups per CU $w: "; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compress-only --workgroups-per-cu $w 2>/dev/null | tail -1 | frac_line; done > ${O}_workgroups_per_cu.txt 2>&1
+  cat ${O}_workgroups_per_cu.txt
+  (AB_MODE=both timeout 500 bash tools/ab.sh "$V" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
+  (AB_MODE=both timeout 500 bash tools/ab.sh "$V" --shape 512,512,512 --dtype float64 2>&1) > ${O}_ab_variants_f64_3d.txt
+  cat ${O}_ab_variants_f64_2d.txt ${O}_ab_variants_f64_3d.txt
+  if [ -f ndzip_amd/_variants/timing.so ]; then
+    (NDZIP_HIP_EXP=16 timeout 300 python bench.py --lib $PWD/ndzip_amd/_variants/timing.so --steps 3 --warmup 1 --no-cpu-baseline --compress-only 2>&1 | tail -40) > ${O}_phase_timing.txt
+    tail -20 ${O}_phase_timing.txt
+  fi
+  TRAFFIC_KEY=float64-8192x8192 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_2d.txt --config 3
+  timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_3d_decode_256.txt --config 5 --f64-work-items 256
+  timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_3d_decode_128.txt --config 5 --f64-work-items 128
+  cp gpurun_out/traffic.json profiles/traffic.json 2>/dev/null
+  ;;
+stress)
+  S=${O}_two_process_stress.txt
+  run() {  # <label> <port> <script> <iterations> [env...]
+    echo "== $1" >> $S
+    env HSA_ENABLE_IPC_MODE_LEGACY=0 "${@:5}" timeout 60 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port $2 $3 $4 >> $S 2>&1
+    rc=$?; echo "exit $rc" >> $S; return $rc
+  }
+  run "steps, synchronised" 29511 tools/sharded_stress_steps.py 10 || { tail -20 $S; exit 0; }
+  run "loop, checked each iteration" 29512 tools/sharded_stress.py 10 CHECK_EACH=1 || { tail -20 $S; exit 0; }
+  run "loop, unsynchronised, 40 iterations" 29513 tools/sharded_stress.py 40 CHECK_EACH=0
+  tail -20 $S
+  ;;
+poll)
+  iv=${3:-900}; what=${4:-first}
+  while true; do
+    if [ -n "$(git status --porcelain ndzip_amd bench.py tests include __graft_entry__.py oracle tools/gpu_batch.sh tools/pmc.sh tools/bench_configs.sh)" ]; then
+      echo "$(date +%T) skip: uncommitted edits"; sleep 120; continue
+    fi
+    lib=ndzip_amd/libndzip_hip.so
+    if [ ! -f $lib ] || [ -n "$(find ndzip_amd/csrc ndzip_amd/build.py -newer $lib -type f | grep -v _build | head -1)" ]; then
+      echo "$(date +%T) skip: library stale"; sleep 120; continue
+    fi
+    /usr/local/graft/bin/gpurun --timeout 3400 -- "bash tools/gpu_batch.sh $what $tag" > /tmp/gpurun_$tag.log 2>&1
+    rc=$?
+    echo "$(date +%T) rc=$rc $(git rev-parse --short HEAD)"
+    if [ $rc -ne 2 ] && [ $rc -ne 3 ]; then echo "RAN at $(git rev-parse --short HEAD)"; tail -60 /tmp/gpurun_$tag.log; exit 0; fi
+    sleep $iv
+  done
+  ;;
+collect)
+  dst=${3:-$tag}
+  for f in rocminfo smoke gputest bench_n1.json configs workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d \
+           rocprofv3_summary_f64_3d_decode_256 rocprofv3_summary_f64_3d_decode_128 ab_variants ab_variants_cfg1 ab_variants_f64_2d \
+           ab_variants_f64_3d phase_timing two_process_stress; do
+    for ext in "" .txt; do
+      [ -f "gpurun_out/${tag}_$f$ext" ] && cp "gpurun_out/${tag}_$f$ext" "profiles/${dst}_$f$ext"
+    done
+  done
+  [ -f gpurun_out/traffic.json ] && cp gpurun_out/traffic.json profiles/traffic.json
+  ls -la profiles/${dst}_* 2>/dev/null
+  ;;
+*) echo "unknown stage $stage"; exit 64;;
+esac
