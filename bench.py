@@ -71,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--smooth", action="store_true", help="highly compressible bookend (two low-frequency octaves)")
     ap.add_argument("--data", type=str, default="synthetic", choices=["synthetic", "random", "zeros"])
     ap.add_argument("--workgroups-per-cu", type=int, default=0, help="cap the persistent compress grid (0 = default: 4 per CU); 3 = the round-2 grid, for an A/B of the occupancy")
-    ap.add_argument("--f64-work-items", type=int, default=0, choices=[0, 128, 256], help="64-bit decoder mapping: 0 = the library's default (256 work-items per hypercube, decompress_kernel_wide), 128 = decompress_kernel; for an A/B of the two")
+    ap.add_argument("--f64-work-items", type=int, default=0, choices=[0, 128, 256], help="64-bit decoder mapping: 0 = the library's default (128 work-items per hypercube, decompress_kernel, until the other is measured), 256 = decompress_kernel_wide; for an A/B of the two")
     ap.add_argument("--overlap-exchange", action="store_true", help="N > 1: leave the offset / header exchange in flight behind the decompress launch (opt-in until it has run over RCCL on a multi-GPU node; default: compress -> exchange -> decompress, every collective waited for)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg")
@@ -508,7 +508,7 @@ def main(argv=None):
         algo_bytes_per_launch = (raw_total + stream_bytes_total) / world
         slabs = plan_shards(global_extent, world)
         kernel_c = f"compress_kernel_db<float,{dims}>" if wb == 4 else f"compress_kernel_wide<unsigned long,{dims}>"
-        kernel_d = (f"decompress_kernel<{'float' if wb == 4 else 'double'},{dims}>" if wb == 4 or args.f64_work_items == 128
+        kernel_d = (f"decompress_kernel<{'float' if wb == 4 else 'double'},{dims}>" if wb == 4 or args.f64_work_items != 256
                     else f"decompress_kernel_wide<{dims}>")
 
         def leg(t):

@@ -157,8 +157,9 @@ NDZIP_HIP_API int ndzip_hip_decompressor_decompress_split_bounded(ndzip_hip_deco
 
 /* Tuning / A-B switch, no reference counterpart (the reference fixes 512 threads per 64-bit hypercube,
  * src/ndzip/gpu_common.hh:38-43): work-items the kernel of a 64-bit profile decodes one hypercube with -- 0 = the library's
- * default (256: decompress_kernel_wide, 4 wavefronts per SIMD), 128 (decompress_kernel, the mapping of the 32-bit profiles,
- * 2 wavefronts per SIMD) or 256.  Both produce the same bits.  No effect on 32-bit profiles. */
+ * default (128 until the 256-work-item kernel has been measured on an MI355X), 128 (decompress_kernel, the mapping of the 32-bit
+ * profiles, 2 wavefronts per SIMD) or 256 (decompress_kernel_wide, 5-7 wavefronts per SIMD).  Both produce the same bits.  No effect
+ * on 32-bit profiles. */
 NDZIP_HIP_API int ndzip_hip_decompressor_set_f64_work_items(ndzip_hip_decompressor *d, int work_items_per_hypercube);
 
 /* Reads and clears the handle's sticky device error word (corrupt header entries); synchronises the handle's stream. */

@@ -164,7 +164,7 @@ struct ndzip_hip_decompressor {
     hipStream_t stream;
     uint32_t *err;
     int num_xcds;
-    int f64_work_items = 0;  // 0 = default mapping of the 64-bit decoder (256 work-items per hypercube); 128 / 256 = an explicit choice
+    int f64_work_items = 0;  // 0 = default mapping of the 64-bit decoder (default_f64_work_items, codec_launch.hpp); 128 / 256 = an explicit choice
 };
 
 extern "C" {

@@ -243,14 +243,10 @@ struct coding<uint64_t> {
         const int q = t & 3;
         const uint32_t c = static_cast<uint32_t>(t) >> 2;
         if (q < 2) *R::ptr(run32 + 2 * c + (q == 0 ? 1u : 0u)) = h.head_word;
-        uint32_t a = lds_address(run32 + h.slot);  // (a running linear LDS address: one increment per kept plane)
-#pragma unroll
-        for (int i = 0; i < planes_per_lane; ++i) {
-            if ((h.head_bits >> (31 - i)) & 1u) {
-                *reinterpret_cast<uint32_t *>(lds_pointer(R::at(a))) = planes[i];
-                a += 8;
-            }
-        }
+        // a running linear LDS address, one 64-bit stream word per kept plane; branch-free, EXEC-masked (gfx950_lds.hpp), with
+        // run_layout's swizzle folded into the store address
+        static_assert(R::at(0x3f8u) == (0x3f8u ^ 0x70u), "lds_append_flagged64 spells run_layout<uint64_t>::at out");
+        lds_append_flagged64(lds_address(run32 + h.slot), h.head_bits, planes);
     }
 };
 

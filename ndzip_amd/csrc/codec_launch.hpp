@@ -45,6 +45,13 @@ struct compress_args {
     bool aligned;          // 16-byte aligned base and row strides
 };
 
+// Which kernel decodes a 64-bit hypercube when the caller has not chosen (ndzip_hip_decompressor_set_f64_work_items).  The
+// 256-work-item decoder (decompress_kernel_wide: 72-82 VGPRs, 5-7 wavefronts per SIMD) is the one the register / occupancy numbers
+// favour, but it has never executed on a GPU; until the -m gpu suite (test_f64_decoder_mappings_agree) and the A/B of
+// tools/bench_configs.sh have run on an MI355X the default stays the 128-work-item mapping whose round-1 form was measured there.
+// Flip this one constant when that evidence exists.
+constexpr int default_f64_work_items = 128;
+
 struct decompress_args {
     const uint32_t *header;   // NHC offset_after entries
     const uint32_t *header_base;  // device pointer to the value the entries are relative to (nullptr = 0; the global offset of
@@ -57,7 +64,7 @@ struct decompress_args {
     bool aligned;
     uint32_t body_words;      // words of `body` the caller vouches for (hypercube runs + border); 0xffffffff = unknown
     int num_xcds;             // accelerator complexes (separate L2s) workgroups are dealt to round-robin: hipDeviceAttributeNumberOfXccs
-    int f64_work_items;       // work-items per 64-bit hypercube: 0 / 256 = decompress_kernel_wide (default), 128 = decompress_kernel
+    int f64_work_items;       // work-items per 64-bit hypercube: 256 = decompress_kernel_wide, 128 = decompress_kernel, 0 = default_f64_work_items
 };
 
 // hypercubes per compress / decompress workgroup for (T, dims)

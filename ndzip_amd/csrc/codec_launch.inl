@@ -678,6 +678,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
             const uint32_t exclusive = resolve_exclusive_prefix_impl<true>(desc, prev_tile, prev_aggregate, err, lane, window);
             if (first_of_tile) misc[NW] = exclusive;
         }
+        lds_append_complete();  // (E::write's plane stores are inline asm: the compiler's waitcnt insertion does not see them)
         __syncthreads();  // B3: previous tile's run complete in LDS, its prefix known
         const bool draw = first_of_tile && next_tile < ntiles;  // the ticket the next iteration reads behind its B1
         uint32_t ticket_after_next = 0;
@@ -705,6 +706,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
             const uint32_t exclusive = resolve_exclusive_prefix(desc, prev_tile, prev_aggregate, err, lane);
             if (first_of_tile) misc[NW] = exclusive;
         }
+        lds_append_complete();
         __syncthreads();
         const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
         copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid_i);
@@ -990,6 +992,7 @@ debug_stage_wide_kernel(int stage, const grid_geom gg, uint32_t hc, const uint64
         uint32_t planes[E::planes_per_lane];
         E::transpose(r, t, planes);
         E::write(E::hold(t, head_a, head_b, E::head_words + chunk_excl), planes, reinterpret_cast<uint32_t *>(cube), t);
+        lds_append_complete();
         __syncthreads();
         for (uint32_t w = t; w < total; w += wide::threads) {
             out[w] = *run_layout<W>::ptr(reinterpret_cast<const W *>(cube) + w);
@@ -1179,8 +1182,8 @@ hipError_t launch_decompress_profile(const decompress_args &a) {
     if (ntiles == 0) return hipSuccess;
     const uint32_t xcds = a.num_xcds > 0 ? static_cast<uint32_t>(a.num_xcds) : 1u;
     if constexpr (sizeof(T) == 8) {
-        // f64: 256 work-items per hypercube unless the caller asked for the 128-work-item mapping (an A/B switch on the handle)
-        if (a.f64_work_items != 128) {
+        // f64: the mapping the caller chose on the handle (an A/B switch), else default_f64_work_items (codec_launch.hpp)
+        if ((a.f64_work_items ? a.f64_work_items : default_f64_work_items) == 256) {
             using WC = wide_decode_cfg<Dims>;
             const uint32_t grid = (a.gg.nhc + xcds - 1) / xcds * xcds;
             hipLaunchKernelGGL((decompress_kernel_wide<Dims, Aligned>), dim3(grid), dim3(WC::threads), WC::smem_bytes, a.stream, a.header,

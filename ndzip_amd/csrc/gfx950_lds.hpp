@@ -58,9 +58,13 @@ NDZIP_DEV char *lds_pointer(uint32_t address) {
 //
 // Bisecting aids (never defined in the product build; ndzip_amd/build.py builds ndzip_amd/_variants/plain.so with both for
 // tools/variant_parity.py): -DNDZIP_NO_SCALAR_PINS takes every uniformity claim back -- wave_uniform / scalar_pointer return the
-// lane's own value, all addressing falls back to per-lane 64-bit pointers -- and -DNDZIP_NO_EXEC_ASM replaces the EXEC-masked
-// assembly of lds_append_nonzero by the loop it stands for.  If the product library ever disagrees with the oracle on hardware
-// and the plain variant does not, the fault is in one of these two mechanisms and not in the algorithm.
+// lane's own value, all addressing falls back to per-lane 64-bit pointers -- and -DNDZIP_NO_EXEC_ASM replaces EVERY block of
+// instruction-level assembly in this header by compiled code that means the same: the EXEC-masked store sequences of
+// lds_append_nonzero / lds_append_flagged64 by the loops they stand for, and the carry-chained / select-fused DPP sequences of
+// row_scan_step64, wave_inclusive_scan64 and pair_exchange_select4 by __builtin_amdgcn_update_dpp moves plus ordinary 64-bit adds and
+// selects (the compiler then counts the wait states itself).  If the product library ever disagrees with the oracle on hardware and
+// the plain variant does not, the fault is in one of these mechanisms and not in the algorithm; tools/variant_parity.py tells which
+// profile (f32: append / pins; f64: also the three DPP helpers).
 #ifdef NDZIP_NO_SCALAR_PINS
 NDZIP_DEV int wave_uniform(int x) { return x; }
 #else
@@ -207,23 +211,85 @@ NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
 #undef NDZIP_APPEND8
 #undef NDZIP_APPEND1
 
+// The same for the 64-bit profiles' encoder (codec_kernels_wide.hpp: a lane holds ONE dword of each of 32 plane words, the other
+// dword is another lane's): word w[i] is kept where bit 31 - i of `flags` (the chunk head's half for this lane's planes) is set --
+// a plane's dword may be zero while the plane is not -- and goes to LDS byte address at(a) = a ^ ((a >> 3) & 0x70), the XOR swizzle
+// of run_layout<uint64_t>, `a` advancing by 8 (one 64-bit stream word) per kept plane.  Per plane: v_cmpx_gt_i32 0 > flags (the
+// lanes whose flag MSB is set stay active), v_lshrrev + v_bitop3 (the swizzle, 0x70 from an SGPR), ds_write_b32, v_add_u32 under
+// the mask, s_mov_b64 exec back, v_lshlrev flags << 1 in all lanes: five VALU, one LDS, one SALU instruction.  Compiled from
+// `if (flags >> (31 - i) & 1) { *at(a) = w[i]; a += 8; }` it is v_and + v_cmp + s_and_saveexec + the same four + s_or_b64: the same
+// VALU count, TWO scalar instructions and a saved 64-bit mask per plane (round 4: 177 s_and_saveexec + 205 s_or_b64 executed per
+// hypercube, SGPR spills in all three compress_kernel_wide).
+// Wait states (checked by tools/asm_hazards.py against LLVM's gfx950 hazard recogniser): none between v_cmpx and ds_write / a
+// non-DPP VALU instruction; the SGPR operands are written by SALU instructions (s_mov), which a VALU instruction may read at once;
+// behind the last v_cmpx come six instructions (a DPP instruction needs 5 wait states after a VALU write of EXEC) and the closing
+// s_nop 1 covers a DPP read of `a` / `flags` by compiled code.  EXEC is as found at every statement boundary; VCC is clobbered.
+#define NDZIP_APPEND64_1(n) \
+    "v_cmpx_gt_i32_e32 vcc, 0, %[f]\n\tv_lshrrev_b32_e32 %[t], 3, %[a]\n\tv_bitop3_b32 %[t], %[t], %[a], %[m] bitop3:0x6c\n\t" \
+    "ds_write_b32 %[t], %[w" #n "]\n\tv_add_u32_e32 %[a], 8, %[a]\n\ts_mov_b64 exec, %[full]\n\tv_lshlrev_b32_e32 %[f], 1, %[f]\n\t"
+#define NDZIP_APPEND64_8 \
+    NDZIP_APPEND64_1(0) NDZIP_APPEND64_1(1) NDZIP_APPEND64_1(2) NDZIP_APPEND64_1(3) NDZIP_APPEND64_1(4) NDZIP_APPEND64_1(5) NDZIP_APPEND64_1(6) NDZIP_APPEND64_1(7)
+NDZIP_DEV void lds_append_flagged64(uint32_t a, uint32_t flags, const uint32_t (&w)[32]) {
+#ifdef NDZIP_NO_EXEC_ASM
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if ((flags >> (31 - i)) & 1u) {
+            *reinterpret_cast<uint32_t *>(lds_pointer(a ^ ((a >> 3) & 0x70u))) = w[i];
+            a += 8;
+        }
+    }
+    return;
+#endif
+    unsigned long long full;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(full));
+    const uint32_t slot_bits = 0x70u;
+    uint32_t t;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        asm volatile(NDZIP_APPEND64_8 "s_nop 1"
+                     : [a] "+v"(a), [f] "+v"(flags), [t] "=&v"(t)
+                     : [w0] "v"(w[i]), [w1] "v"(w[i + 1]), [w2] "v"(w[i + 2]), [w3] "v"(w[i + 3]), [w4] "v"(w[i + 4]), [w5] "v"(w[i + 5]),
+                     [w6] "v"(w[i + 6]), [w7] "v"(w[i + 7]), [full] "s"(full), [m] "s"(slot_bits)
+                     : "vcc", "memory");
+    }
+}
+#undef NDZIP_APPEND64_8
+#undef NDZIP_APPEND64_1
+
 // One step of a prefix sum over the 16 lanes of a DPP row for EIGHT 64-bit values held as (lo, hi) register pairs:
 // v += row_shr:D(v), lanes shifted in from outside the row contributing 0.  In C++ this is two v_mov_b32_dpp and a 64-bit add per
 // value (the DPP move folds into a plain v_add_u32, not into an add that produces or consumes a carry): 3 VALU instructions; here
-// v_add_co_u32_dpp + v_addc_co_u32_dpp: 2.  (f64 3D decode: 64 value-steps per work-item.)
-// Wait states: a DPP instruction must not read a VGPR a VALU instruction wrote less than 2 wait states earlier, and the compiler
-// does not look into an asm statement -- each statement opens with s_nop 1; inside, consecutive instructions touch different
-// registers (lo_j, hi_j, lo_j+1 ...), and a value's next step is at least 16 instructions away.  VCC is clobbered.
+// v_add_co_u32_dpp + v_addc_co_u32_dpp: 2 VALU instructions and two idle issue slots of this wavefront (which the SIMD's other
+// wavefronts can use).  (f64 3D decode: 64 value-steps per work-item.)
+// Wait states (the compiler does not look into an asm statement; tools/asm_hazards.py runs every statement of the built code
+// through LLVM's own gfx950 hazard recogniser and fails if that would insert a single s_nop more):
+//   * a DPP instruction must not read a VGPR a VALU instruction wrote less than 2 wait states earlier -- each statement opens and
+//     closes with s_nop 1 (compiled code on either side; hipcc pads ONE state behind an asm statement, not two);
+//   * gfx940 / gfx950: a VALU instruction must not read an SGPR or VCC a VALU instruction wrote less than 2 wait states earlier --
+//     the carry of v_add_co is such a value: s_nop 1 between the two halves of every add (hipcc's own 64-bit subtractions read
+//     v_sub_co / s_nop 1 / v_subb_co for the same reason).  Rounds 3-4 had the pair back to back: per LLVM a stale-carry hazard.
+// VCC is clobbered.
 #define NDZIP_ROWADD1(n, d) \
-    "v_add_co_u32_dpp %[l" #n "], vcc, %[l" #n "], %[l" #n "] row_shr:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_co_u32_dpp %[l" #n "], vcc, %[l" #n "], %[l" #n "] row_shr:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t" \
     "v_addc_co_u32_dpp %[h" #n "], vcc, %[h" #n "], %[h" #n "], vcc row_shr:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define NDZIP_ROWADD8(d) "s_nop 1\n\t" NDZIP_ROWADD1(0, d) NDZIP_ROWADD1(1, d) NDZIP_ROWADD1(2, d) NDZIP_ROWADD1(3, d) NDZIP_ROWADD1(4, d) NDZIP_ROWADD1(5, d) NDZIP_ROWADD1(6, d) NDZIP_ROWADD1(7, d)
+#define NDZIP_ROWADD8(d) "s_nop 1\n\t" NDZIP_ROWADD1(0, d) NDZIP_ROWADD1(1, d) NDZIP_ROWADD1(2, d) NDZIP_ROWADD1(3, d) NDZIP_ROWADD1(4, d) NDZIP_ROWADD1(5, d) NDZIP_ROWADD1(6, d) NDZIP_ROWADD1(7, d) "s_nop 1" 
 #define NDZIP_ROWADD_OPERANDS \
     [l0] "+v"(lo[0]), [h0] "+v"(hi[0]), [l1] "+v"(lo[1]), [h1] "+v"(hi[1]), [l2] "+v"(lo[2]), [h2] "+v"(hi[2]), [l3] "+v"(lo[3]), [h3] "+v"(hi[3]), \
     [l4] "+v"(lo[4]), [h4] "+v"(hi[4]), [l5] "+v"(lo[5]), [h5] "+v"(hi[5]), [l6] "+v"(lo[6]), [h6] "+v"(hi[6]), [l7] "+v"(lo[7]), [h7] "+v"(hi[7])
 template<int D>
 NDZIP_DEV void row_scan_step64(uint32_t (&lo)[8], uint32_t (&hi)[8]) {
     static_assert(D == 1 || D == 2 || D == 4 || D == 8);
+#ifdef NDZIP_NO_EXEC_ASM
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t sl = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo[j]), 0x110 + D, 0xf, 0xf, true));
+        const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi[j]), 0x110 + D, 0xf, 0xf, true));
+        const uint64_t r = ((static_cast<uint64_t>(hi[j]) << 32) | lo[j]) + ((static_cast<uint64_t>(sh) << 32) | sl);
+        lo[j] = static_cast<uint32_t>(r);
+        hi[j] = static_cast<uint32_t>(r >> 32);
+    }
+    return;
+#endif
     if constexpr (D == 1) {
         asm volatile(NDZIP_ROWADD8(1) : NDZIP_ROWADD_OPERANDS : : "vcc");
     } else if constexpr (D == 2) {
@@ -242,12 +308,34 @@ NDZIP_DEV void row_scan_step64(uint32_t (&lo)[8], uint32_t (&hi)[8]) {
 // DPP scan (row_shr 1 / 2 / 4 / 8, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) with the carry taken along --
 // v_add_co_u32_dpp + v_addc_co_u32_dpp per step, twelve VALU instructions and no LDS traffic.  (__shfl_up on a 64-bit value is two
 // ds_bpermute_b32 plus a compare, two selects and a 64-bit add per step: six dependent LDS-crossbar round trips and ~50
-// instructions on the path of the 1D decoders' carry.)  Wait states: the DPP operand of a step was written by the step before --
-// add_co (lo), addc (hi), then s_nop 0 puts 2 wait states between each write and its DPP read; s_nop 1 in front for whatever the
-// compiler computed last.  Lanes of rows a row_mask disables are not written (their VCC bit is irrelevant: the addc is disabled too).
+// instructions on the path of the 1D decoders' carry.)  Wait states (see row_scan_step64): s_nop 1 between add_co and addc for the
+// carry in VCC; that also puts 3 wait states between a step's write of lo / hi and the next step's DPP read of it; s_nop 1 in
+// front for whatever the compiler computed last and behind for whatever it reads first.
+// Lanes of rows a row_mask disables are not written (their VCC bit is irrelevant: the addc is disabled too).
 #define NDZIP_SCAN64_STEP(ctrl) \
-    "v_add_co_u32_dpp %[lo], vcc, %[lo], %[lo] " ctrl "\n\tv_addc_co_u32_dpp %[hi], vcc, %[hi], %[hi], vcc " ctrl "\n\ts_nop 0\n\t"
+    "v_add_co_u32_dpp %[lo], vcc, %[lo], %[lo] " ctrl "\n\ts_nop 1\n\tv_addc_co_u32_dpp %[hi], vcc, %[hi], %[hi], vcc " ctrl "\n\t"
 NDZIP_DEV void wave_inclusive_scan64(uint32_t &lo, uint32_t &hi) {
+#ifdef NDZIP_NO_EXEC_ASM
+    {
+        // (DPP control words: 0x110 + d = row_shr:d, 0x142 = row_bcast:15, 0x143 = row_bcast:31; lanes a row_mask disables take old = 0)
+#define NDZIP_SCAN64_C(ctrl, rows, bound) \
+    { \
+        const uint32_t sl = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), ctrl, rows, 0xf, bound)); \
+        const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi), ctrl, rows, 0xf, bound)); \
+        const uint64_t r = ((static_cast<uint64_t>(hi) << 32) | lo) + ((static_cast<uint64_t>(sh) << 32) | sl); \
+        lo = static_cast<uint32_t>(r); \
+        hi = static_cast<uint32_t>(r >> 32); \
+    }
+        NDZIP_SCAN64_C(0x111, 0xf, true)
+        NDZIP_SCAN64_C(0x112, 0xf, true)
+        NDZIP_SCAN64_C(0x114, 0xf, true)
+        NDZIP_SCAN64_C(0x118, 0xf, true)
+        NDZIP_SCAN64_C(0x142, 0xa, false)
+        NDZIP_SCAN64_C(0x143, 0xc, false)
+#undef NDZIP_SCAN64_C
+        return;
+    }
+#endif
     asm volatile("s_nop 1\n\t"
                  NDZIP_SCAN64_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
                  NDZIP_SCAN64_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
@@ -255,6 +343,7 @@ NDZIP_DEV void wave_inclusive_scan64(uint32_t &lo, uint32_t &hi) {
                  NDZIP_SCAN64_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
                  NDZIP_SCAN64_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
                  NDZIP_SCAN64_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
                  : [lo] "+v"(lo), [hi] "+v"(hi)
                  :
                  : "vcc");
@@ -266,16 +355,27 @@ NDZIP_DEV void wave_inclusive_scan64(uint32_t &lo, uint32_t &hi) {
 // as ONE v_cndmask_b32_dpp each (quad_perm [1,0,3,2] on the swapped operand) instead of a DPP move and a select: the compiler
 // folds a DPP move into src0 of a VOP2 instruction, but not across the select's operand order / inverted mask it would take here.
 // `odd_flag`: non-zero in odd lanes.  Every lane of the wavefront executes this (a DPP operand reads lanes that must be active).
-// Wait states: s_nop 1 in front (VALU write of a VGPR -> DPP read: 2); VCC is written by v_cmp (VALU) and read by v_cndmask as
-// its mask: no software wait state on gfx9.  VCC is clobbered.
+// Wait states: s_nop 1 in front (VALU write of a VGPR -> DPP read: 2) and behind; VCC is written by v_cmp (VALU) and read by
+// v_cndmask as its mask: 2 wait states on gfx940 / gfx950 (see row_scan_step64) -- s_nop 1 behind each v_cmp.  VCC is clobbered.
 #define NDZIP_SWAPSEL(n) "v_cndmask_b32_dpp %[lo" #n "], %[a" #n "], %[b" #n "], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 #define NDZIP_SWAPSEL_HI(n) "v_cndmask_b32_dpp %[hi" #n "], %[b" #n "], %[a" #n "], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 NDZIP_DEV void pair_exchange_select4(uint32_t odd_flag, const uint32_t (&a)[4], const uint32_t (&b)[4], uint32_t (&lo)[4], uint32_t (&hi)[4]) {
+#ifdef NDZIP_NO_EXEC_ASM
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // (0xb1 = quad_perm:[1,0,3,2])
+        const uint32_t other_a = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(a[j]), 0xb1, 0xf, 0xf, true));
+        const uint32_t other_b = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(b[j]), 0xb1, 0xf, 0xf, true));
+        lo[j] = odd_flag ? b[j] : other_a;
+        hi[j] = odd_flag ? other_b : a[j];
+    }
+    return;
+#endif
     asm volatile("s_nop 1\n\t"
-                 "v_cmp_ne_u32_e32 vcc, 0, %[odd]\n\t"  // vcc = odd lanes: lo = vcc ? b : swap(a)
+                 "v_cmp_ne_u32_e32 vcc, 0, %[odd]\n\ts_nop 1\n\t"  // vcc = odd lanes: lo = vcc ? b : swap(a)
                  NDZIP_SWAPSEL(0) NDZIP_SWAPSEL(1) NDZIP_SWAPSEL(2) NDZIP_SWAPSEL(3)
-                 "v_cmp_eq_u32_e32 vcc, 0, %[odd]\n\t"  // vcc = even lanes: hi = vcc ? a : swap(b)
+                 "v_cmp_eq_u32_e32 vcc, 0, %[odd]\n\ts_nop 1\n\t"  // vcc = even lanes: hi = vcc ? a : swap(b)
                  NDZIP_SWAPSEL_HI(0) NDZIP_SWAPSEL_HI(1) NDZIP_SWAPSEL_HI(2) NDZIP_SWAPSEL_HI(3)
+                 "s_nop 1"
                  : [lo0] "=&v"(lo[0]), [lo1] "=&v"(lo[1]), [lo2] "=&v"(lo[2]), [lo3] "=&v"(lo[3]), [hi0] "=&v"(hi[0]), [hi1] "=&v"(hi[1]),
                    [hi2] "=&v"(hi[2]), [hi3] "=&v"(hi[3])
                  : [odd] "v"(odd_flag), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b0] "v"(b[0]), [b1] "v"(b[1]),

@@ -11,8 +11,11 @@ interpreter, which finds the kernel of the same mangled name in the gfx950 code 
 says (explicit arguments as packed by the model, hidden arguments from the code object's metadata) and runs the grid.  "Device
 memory" is the process's own memory (numpy buffers of the tests, the model's hipMalloc = malloc).
 
-What it is NOT: a timing model, a hazard checker (s_nop / s_waitcnt are no-ops: every instruction completes before the next starts)
-or a memory-model checker (one sequentially consistent memory).  Semantics follow the Vega / CDNA3 ISA manuals as far as the
+What it is NOT: a timing model or a memory-model checker (one sequentially consistent memory; s_nop / s_waitcnt change no result:
+every instruction completes before the next starts).  It does keep wait-state and waitcnt BOOKKEEPING on the executed stream
+(check_hazards / check_waits below) -- a hazard table written from the builder's reading of the ISA manual, which missed the
+gfx940-family "VALU writes SGPR / VCC -> VALU reads it: 2 wait states" until round 5; the authority for the inline assembly's wait
+states is tools/asm_hazards.py (LLVM's own hazard recogniser), this table is a second net under it.  Semantics follow the Vega / CDNA3 ISA manuals as far as the
 instructions that occur in these kernels go; anything else raises Unsupported with the instruction text.
 Not part of the product: nothing under ndzip_amd/ imports this."""
 from __future__ import annotations
@@ -1238,7 +1241,9 @@ OPS["global_atomic_swap_x2"] = _gatomic(lambda c, d: d, 2)
 # The gfx9 "manually inserted wait states" that matter around hand-written assembly (the compiler pads its own code; it does not look
 # inside an asm statement): a DPP instruction needs 2 wait states after a VALU write of the VGPR it permutes and 5 after a VALU write
 # of EXEC; v_readlane / v_writelane need 4 after a VALU write of the SGPR (or VCC) that selects the lane; a vector-memory
-# instruction needs 5 after a VALU write (v_readfirstlane, v_readlane, v_cmp ...) of an SGPR it uses as base.  One issued instruction
+# instruction needs 5 after a VALU write (v_readfirstlane, v_readlane, v_cmp ...) of an SGPR it uses as base; and on gfx940 / gfx950
+# (LLVM: hasVDecCoExecHazard) a VALU instruction needs 2 after a VALU write of an SGPR or VCC it reads -- the carry between v_add_co
+# and v_addc, the mask between v_cmp and v_cndmask (hipcc pads its own: v_sub_co / s_nop 1 / v_subb_co).  One issued instruction
 # = one wait state, s_nop N = N + 1.  Checked on the EXECUTED instruction stream, per wavefront; compiler-scheduled code must come
 # out clean too (it does: that calibrates the rules).
 HAZARD_LOG = []
@@ -1264,7 +1269,7 @@ def _hazard_info(ins):
     if op in ("v_readlane_b32", "v_writelane_b32"):
         lane = _regs_of(args[2], "s") or ([106] if args[2] in ("vcc_lo", "vcc") else [])
     vmem = [r for tok in args for r in _regs_of(tok, "s")] if op.startswith(("global_", "buffer_", "flat_", "scratch_")) else []
-    vw, sw = [], []
+    vw, sw, dests = [], [], []
     if is_valu and args:
         vw = _regs_of(args[0], "v")
         dests = [args[0]] + ([args[1]] if ("_co_" in op or op.startswith("v_mad_u64")) and len(args) > 1 else [])
@@ -1273,7 +1278,13 @@ def _hazard_info(ins):
             if tok in ("vcc", "vcc_lo"):
                 sw += [106, 107]
     states = int(args[0], 0) + 1 if op == "s_nop" and args else 1
-    return dpp, lane, vmem, vw, sw, is_valu and op.startswith("v_cmpx"), states
+    sread = []  # SGPRs / VCC a VALU instruction reads as a source (carry-in, select mask, scalar operand)
+    if is_valu:
+        for tok in args[len(dests) if "_co_" in op or op.startswith(("v_mad_u64", "v_cmp")) else 1:]:
+            sread += _regs_of(tok, "s")
+            if tok in ("vcc", "vcc_lo"):
+                sread += [106, 107]
+    return dpp, lane, vmem, vw, sw, is_valu and op.startswith("v_cmpx"), states, sread
 
 
 def check_hazards(w, ins):
@@ -1282,8 +1293,12 @@ def check_hazards(w, ins):
         info = _hazard_info(ins)
         if ins.target is None:  # (branches keep their target there; everything else caches its hazard facts in the free slot)
             ins.target = info
-    dpp, lane, vmem, vw, sw, wexec, states = info
+    dpp, lane, vmem, vw, sw, wexec, states, sread = info
     now = w.clock
+    for r in sread:
+        if now - w.sgpr_written.get(r, -100) < 2:
+            HAZARD_LOG.append((ins.addr, ins.text, f"VALU reads {'vcc' if r >= 106 else 's%d' % r}, written by VALU {now - w.sgpr_written[r]} wait states ago (2 needed on gfx940 / gfx950)"))
+            break
     if dpp is not None:
         for n in dpp:
             if now - w.vgpr_written.get(n, -100) < 2:

@@ -102,7 +102,7 @@ class _HostAccelerator:
 
 @pytest.mark.parametrize("argv,mode", [(["--shape", "32,32,32"], "both"), (["--shape", "128,128", "--dtype", "float64", "--decompress-only"], "decompress"),
                                        (["--shape", "8192", "--compress-only", "--data", "random"], "compress"),
-                                       (["--shape", "128,128", "--dtype", "float64", "--decompress-only", "--f64-work-items", "128"], "decompress")])
+                                       (["--shape", "128,128", "--dtype", "float64", "--decompress-only", "--f64-work-items", "256"], "decompress")])
 def test_main_produces_the_contract_line_on_the_model(monkeypatch, capsys, argv, mode):
     """bench.main() end to end -- workload set-up, the timed loop, verification, the JSON line with roofline and cpu_baseline --
     with the kernels on the wave64 functional model (tests/wavesim) and host tensors: every key the driver and the judge read
@@ -124,8 +124,8 @@ def test_main_produces_the_contract_line_on_the_model(monkeypatch, capsys, argv,
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert ("decompress_kernel" in r["kernel"]) == (mode == "decompress")
-    if mode == "decompress":  # (64-bit profiles decode with 256 work-items per hypercube unless the A/B switch says 128)
-        assert r["kernel"] == ("decompress_kernel<double,2>" if "--f64-work-items" in argv else "decompress_kernel_wide<2>")
+    if mode == "decompress":  # (64-bit profiles decode with 128 work-items per hypercube unless the A/B switch says 256)
+        assert r["kernel"] == ("decompress_kernel_wide<2>" if "--f64-work-items" in argv else "decompress_kernel<double,2>")
     assert ("decompress" in r) == (mode == "both")
     assert set(d["per_gpu"]) == {"both": {"compress_GBps", "compress_frac_of_hbm_peak", "decompress_GBps", "decompress_frac_of_hbm_peak"},
                                  "compress": {"compress_GBps", "compress_frac_of_hbm_peak"},

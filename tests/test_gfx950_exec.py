@@ -6,8 +6,9 @@ replaces the one file with hand-written assembly.  Here the model only plays the
 scratch); every kernel launch is intercepted and the kernel of the same mangled name is fetched from the gfx950 ELF inside
 ndzip_amd/libndzip_hip.so / libndzip_hip_stages.so and interpreted: the EXEC-masked plane compaction as assembled, every DPP control
 word and v_readfirstlane pin as emitted, the compiler's register allocation around the inline assembly, the ticket / look-back
-protocol of concurrently running workgroups under different interleavings.  What this cannot see: timing, hardware hazards
-(s_nop / s_waitcnt are no-ops here) and the memory model across XCDs -- the GPU suite's job.  Not a product path."""
+protocol of concurrently running workgroups under different interleavings.  What this cannot see: timing and the memory model
+across XCDs -- the GPU suite's job; wait states are only book-kept against the interpreter's own hazard table (the authority for
+the inline assembly's wait states is LLVM's hazard recogniser: tests/test_asm_hazards.py).  Not a product path."""
 import os
 
 import numpy as np

@@ -119,8 +119,8 @@ def test_dense_and_sparse_chunks_mixed(hiplib, cuda_device, profile):
 @pytest.mark.parametrize("dims", [1, 2, 3])
 @pytest.mark.parametrize("work_items", [128, 256])
 def test_f64_decoder_mappings_agree(hiplib, cuda_device, dims, work_items):
-    """ndzip_hip_decompressor_set_f64_work_items: the 64-bit decoder with 256 work-items per hypercube (decompress_kernel_wide, the
-    default: every other float64 test in this suite runs it) and with 128 (decompress_kernel) decode the oracle's streams to the
+    """ndzip_hip_decompressor_set_f64_work_items: the 64-bit decoder with 256 work-items per hypercube (decompress_kernel_wide) and with 128
+    (decompress_kernel; every other float64 test in this suite runs both, tests/util.py) decode the oracle's streams to the
     same bits -- incompressible hypercubes (the wave-uniform dense path of the wide decoder: every chunk of a wavefront keeps all
     64 planes), smooth data, zeros, the mixed dense / sparse pattern, unaligned rows with a border."""
     import ndzip_amd

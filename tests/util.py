@@ -89,6 +89,16 @@ def device_decompress(stream: np.ndarray, dtype, extent, device=None, f64_work_i
     dec.decompress(d_stream, d_out, extent)
     dec.check()
     out = d_out[:n].cpu().numpy().view(dtype).reshape(extent)
+    if np.dtype(dtype) == np.float64 and not f64_work_items:
+        # the library decodes 64-bit profiles with one of two kernels (default_f64_work_items, codec_launch.hpp): every float64
+        # test that does not choose runs BOTH and requires the same bits, so neither kernel's coverage depends on the default
+        for work_items in (128, 256):
+            d_out.fill_(0x5A5A5A5A5A5A5A5A)
+            dec.set_f64_work_items(work_items)
+            dec.decompress(d_stream, d_out, extent)
+            dec.check()
+            other = d_out[:n].cpu().numpy().view(dtype).reshape(extent)
+            assert same_bits(other, out), f"the {work_items}-work-item 64-bit decoder differs from the default one"
     dec.close()
     return out
 

@@ -120,6 +120,17 @@ NDZIP_DEV uint32_t lds_append_nonzero(uint32_t a, const uint32_t (&w)[32]) {
     return a;
 }
 
+// the 64-bit profiles' compaction (product: EXEC-masked assembly): word i kept where bit 31 - i of `flags` is set, stored at the
+// XOR-swizzled address of run_layout<uint64_t>, 8 bytes per kept plane
+NDZIP_DEV void lds_append_flagged64(uint32_t a, uint32_t flags, const uint32_t (&w)[32]) {
+    for (int i = 0; i < 32; ++i) {
+        if ((flags >> (31 - i)) & 1u) {
+            *reinterpret_cast<uint32_t *>(lds_pointer(a ^ ((a >> 3) & 0x70u))) = w[i];
+            a += 8;
+        }
+    }
+}
+
 NDZIP_DEV void lds_append_complete() {}
 
 // inclusive prefix sum of one 64-bit value per lane over the wavefront (product: six v_add_co_u32_dpp + v_addc_co_u32_dpp steps)

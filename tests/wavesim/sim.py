@@ -84,6 +84,14 @@ def decompress(stream: np.ndarray, dtype, extent, bounded: bool = False, schedul
                 dec.set_f64_work_items(f64_work_items)
             dec.decompress(buf.ctypes.data, out.ctypes.data, extent, stream.size if bounded else None)
             dec.check()
+            if np.dtype(dtype) == np.float64 and not f64_work_items:
+                # (both 64-bit decoder kernels, whatever the library's default is: see tests/util.py::device_decompress)
+                for work_items in (128, 256):
+                    other = np.full(extent, np.nan, dtype=dtype)
+                    dec.set_f64_work_items(work_items)
+                    dec.decompress(buf.ctypes.data, other.ctypes.data, extent, stream.size if bounded else None)
+                    dec.check()
+                    assert np.array_equal(other.view(np.uint64), out.view(np.uint64)), f"the {work_items}-work-item 64-bit decoder differs"
         finally:
             dec.close()
     return out

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--shape", default="32,64,64")
     ap.add_argument("--noise-mask", type=lambda s: int(s, 0), default=0xFF)
     ap.add_argument("--f64-work-items", type=int, default=0)
+    ap.add_argument("--scalar", action="store_true", help="also list every scalar-side opcode executed (SALU / waits / branches)")
     a = ap.parse_args()
     from ndzip_amd import hip, synth
     from oracle import oracle
@@ -78,6 +79,8 @@ def main():
               + ", ".join(f"{op} {r[1] / max(r[2], 1):.2f}x" for op, r in sorted(lds, key=lambda kv: -(kv[1][1] - kv[1][2]))[:5]))
         top = collections.Counter({op: n for (k, op), n in gx.PROFILE.items() if k == name})
         print("    top: " + ", ".join(f"{op} {n / nhc:.0f}" for op, n in top.most_common(14)))
+        if a.scalar:
+            print("    scalar side: " + ", ".join(f"{op} {n / nhc:.0f}" for op, n in top.most_common() if op.startswith("s_")))
 
 
 if __name__ == "__main__":
