@@ -291,6 +291,40 @@ def cpu_reference_serial(sample, what):
     }
 
 
+def cpu_port_serial(sample, what):
+    """The C restatement of the reference CPU codec (oracle/ndzip_oracle.c), one thread: what stands in for the reference tool's
+    `-e cpu -T 1` when oracle/_ref did not reach the box."""
+    import numpy as np
+
+    from oracle import oracle
+
+    oracle.decompress(oracle.compress(sample, 1), sample.dtype, sample.shape, 1)  # untimed: code and pages warm
+    tc, td = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        s = oracle.compress(sample, 1)
+        t1 = time.perf_counter()
+        back = oracle.decompress(s, sample.dtype, sample.shape, 1)
+        back = back[0] if isinstance(back, tuple) else back
+        t2 = time.perf_counter()
+        tc.append(t1 - t0)
+        td.append(t2 - t1)
+    wdt = np.uint32 if sample.itemsize == 4 else np.uint64
+    c, d = sample.nbytes / float(np.median(tc)) / 1e9, sample.nbytes / float(np.median(td)) / 1e9
+    return {
+        "value": round(2.0 / (1.0 / c + 1.0 / d), 3),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{what} ({sample.nbytes >> 20} MiB), C restatement of the reference serial CPU path (oracle/ndzip_oracle.c: scalar C, the "
+                  f"reference is AVX2), one thread, median of 3",
+        "compress_GBps": round(c, 3),
+        "decompress_GBps": round(d, 3),
+        "ratio": round(len(s) * s.itemsize / sample.nbytes, 4),
+        "roundtrip_ok": bool(np.array_equal(np.asarray(back).view(wdt).reshape(-1), sample.view(wdt).reshape(-1))),
+    }
+
+
 def cpu_legs(host_grid, budget_s):
     """-> dict of the CPU objects of the JSON line.  `host_grid`: a bounded sample of the benchmarked workload."""
     import numpy as np
@@ -325,6 +359,10 @@ def cpu_legs(host_grid, budget_s):
                 "reference")
     else:
         guarded("cpu_baseline", lambda: cpu_port_openmp(host_grid, cores, budget_s), "port")
+        # BASELINE configs[0] has a line either way: with the port when the compiled reference is not there
+        cfg1 = synth_numpy((1 << 24,), np.float32, seed=3, noise_mask=0xFF)
+        guarded("cpu_port_serial_cfg1",
+                lambda: cpu_port_serial(cfg1, "BASELINE configs[0]: 1D float32 16 Mi elements (Appendix-B generator seed 3, noise_mask 0xff)"), "port")
     if isinstance(out.get("cpu_baseline"), dict):
         out["cpu_baseline"]["why_kind"] = why
     return out

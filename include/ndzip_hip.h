@@ -103,12 +103,15 @@ NDZIP_HIP_API int ndzip_hip_compressor_offset_header(ndzip_hip_compressor *c, ui
 NDZIP_HIP_API int ndzip_hip_compressor_offset_header_device(
         ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, const uint32_t *d_base);
 
-/* The same with the base computed on the device from the all-gathered shard lengths: base of shard `rank` = sum over
- * r < rank of (d_lengths[r] - d_borders[r]) (words written by compress_split incl. the shard's border, minus its border
- * words); the base is also stored to *d_base_out (may be NULL) for ndzip_hip_decompressor_decompress_split.  One launch
- * between the two collectives of the multi-GPU path, no host synchronisation. */
+/* The same with the base computed on the device from the all-gathered shard lengths (`world` entries each): base of shard
+ * `rank` = sum over r < rank of (d_lengths[r] - d_borders[r]) (words written by compress_split incl. the shard's border, minus
+ * its border words); the base is also stored to *d_base_out (may be NULL) for ndzip_hip_decompressor_decompress_split.  One
+ * launch between the two collectives of the multi-GPU path, no host synchronisation.
+ * Stream offsets are index_type = uint32 (include/ndzip/ndzip.hh:20): the sums are taken in 64 bits over ALL `world` shards, and
+ * when the hypercube runs of the whole plan exceed 2^32 - 1 words the handle's error word gets the bit that
+ * ndzip_hip_compressor_check reports as "sharded stream exceeds the format's 32-bit offsets" -- on every rank alike. */
 NDZIP_HIP_API int ndzip_hip_compressor_offset_header_gathered(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count,
-        const uint32_t *d_lengths, const uint32_t *d_borders, uint32_t rank, uint32_t *d_base_out);
+        const uint32_t *d_lengths, const uint32_t *d_borders, uint32_t rank, uint32_t world, uint32_t *d_base_out);
 
 /* Reads and clears the handle's sticky device error word; synchronises the handle's stream.  MANDATORY at the caller's
  * first host synchronisation after a compress call when the stream is going to be kept: a look-back timeout (a device

@@ -96,13 +96,24 @@ __global__ void offset_header_device_kernel(uint32_t *header, uint32_t count, co
 }
 
 // base of shard `rank` = sum over lower ranks of (body words incl. border - border words), from the all-gathered lengths;
-// added to the shard's header entries and left in *base_out for the decoder (one launch instead of a dozen tensor ops)
+// added to the shard's header entries and left in *base_out for the decoder (one launch instead of a dozen tensor ops).
+// Offsets of the stream format are index_type = uint32 (include/ndzip/ndzip.hh:20, common.hh:342-347): `world` legal shards can
+// add up to hypercube runs the format cannot address.  The sums are taken in 64 bits over ALL shards, so every rank of the plan
+// sets err_offset_overflow in its error word for the same inputs (SURVEY 8e "keep u64 internally and check overflow").
+constexpr uint32_t err_offset_overflow_bit = 4u;
 __global__ void offset_header_gathered_kernel(uint32_t *header, uint32_t count, const uint32_t *lengths, const uint32_t *borders,
-        uint32_t rank, uint32_t *base_out) {
-    uint32_t base = 0;
-    for (uint32_t r = 0; r < rank; ++r) base += lengths[r] - borders[r];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += base;
-    if (base_out && blockIdx.x == 0 && threadIdx.x == 0) *base_out = base;
+        uint32_t rank, uint32_t world, uint32_t *base_out, uint32_t *err) {
+    uint64_t base = 0, total = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        if (r == rank) base = total;
+        total += static_cast<uint64_t>(lengths[r]) - borders[r];
+    }
+    const uint32_t base32 = static_cast<uint32_t>(base);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += base32;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (base_out) *base_out = base32;
+        if (total > 0xffffffffull) atomicOr(err, err_offset_overflow_bit);
+    }
 }
 
 template<bool Pack>
@@ -125,7 +136,7 @@ hipError_t launch_border(int dtype, void *data, void *body, const uint32_t *head
 }
 
 // error word bits
-constexpr uint32_t err_lookback_timeout = 1u, err_corrupt_header = 2u;
+constexpr uint32_t err_lookback_timeout = 1u, err_corrupt_header = 2u, err_offset_overflow = err_offset_overflow_bit;
 
 int check_error_word(uint32_t *d_err, hipStream_t stream, uint32_t *bits = nullptr) {
     uint32_t host = 0;
@@ -135,9 +146,10 @@ int check_error_word(uint32_t *d_err, hipStream_t stream, uint32_t *bits = nullp
     if (bits) *bits = host;
     if (host != 0) {
         HIP_TRY(hipMemsetAsync(d_err, 0, sizeof host, stream));
-        char buf[160];
-        snprintf(buf, sizeof buf, "device error word 0x%x (%s%s)", host, (host & err_lookback_timeout) ? "scan look-back timeout " : "",
-                (host & err_corrupt_header) ? "corrupt stream header" : "");
+        char buf[224];
+        snprintf(buf, sizeof buf, "device error word 0x%x (%s%s%s)", host, (host & err_lookback_timeout) ? "scan look-back timeout " : "",
+                (host & err_corrupt_header) ? "corrupt stream header " : "",
+                (host & err_offset_overflow) ? "sharded stream exceeds the format's 32-bit offsets" : "");
         return fail(NDZIP_HIP_ERR_DEVICE_FAULT, buf);
     }
     return NDZIP_HIP_OK;
@@ -312,13 +324,14 @@ int ndzip_hip_compressor_offset_header_device(ndzip_hip_compressor *c, uint32_t 
 }
 
 int ndzip_hip_compressor_offset_header_gathered(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count, const uint32_t *d_lengths,
-        const uint32_t *d_borders, uint32_t rank, uint32_t *d_base_out) {
+        const uint32_t *d_borders, uint32_t rank, uint32_t world, uint32_t *d_base_out) {
     if (!c || (!d_header && count) || !d_lengths || !d_borders) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (rank >= world) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "rank outside the plan");
     uint32_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;  // still publishes the base
     hipLaunchKernelGGL(offset_header_gathered_kernel, dim3(blocks), dim3(256), 0, c->stream, d_header, count, d_lengths, d_borders, rank,
-            d_base_out);
+            world, d_base_out, c->err);
     HIP_TRY(hipGetLastError());
     return NDZIP_HIP_OK;
 }

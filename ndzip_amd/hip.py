@@ -166,7 +166,7 @@ def _bind(L, strict: bool = True):
     L.ndzip_hip_compressor_compress_split.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _U32P, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ndzip_hip_compressor_offset_header.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     L.ndzip_hip_compressor_offset_header_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
-    L.ndzip_hip_compressor_offset_header_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ndzip_hip_compressor_offset_header_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.ndzip_hip_compressor_check.argtypes = [C.c_void_p]
     L.ndzip_hip_compressor_set_max_workgroups_per_cu.argtypes = [C.c_void_p, C.c_int]
     L.ndzip_hip_decompressor_set_f64_work_items.argtypes = [C.c_void_p, C.c_int]
@@ -306,9 +306,9 @@ class HipCompressor:
     def offset_header_device(self, device_header, count: int, device_base) -> None:
         _check(lib().ndzip_hip_compressor_offset_header_device(self._h, _ptr(device_header), count, _ptr(device_base)))
 
-    def offset_header_gathered(self, device_header, count: int, device_lengths, device_borders, rank: int, device_base_out=None) -> None:
+    def offset_header_gathered(self, device_header, count: int, device_lengths, device_borders, rank: int, world: int, device_base_out=None) -> None:
         _check(lib().ndzip_hip_compressor_offset_header_gathered(self._h, _ptr(device_header), count, _ptr(device_lengths),
-                                                                 _ptr(device_borders), rank, _ptr(device_base_out)))
+                                                                 _ptr(device_borders), rank, world, _ptr(device_base_out)))
 
     def check(self) -> None:
         _check(lib().ndzip_hip_compressor_check(self._h))

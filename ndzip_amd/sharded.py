@@ -93,13 +93,39 @@ def gather_headers(local_header, shard_sizes: Sequence[int], world: int, group=N
     return torch.cat([out[r * m: r * m + shard_sizes[r]] for r in range(world)])
 
 
+INDEX_MAX = 0xFFFFFFFF  # index_type = uint32 (include/ndzip/ndzip.hh:20): element counts and stream offsets of the format
+
+
 def base_from_lengths(lengths, borders, rank: int) -> int:
-    """Global word offset of shard `rank`'s body: sum over lower ranks of (words written incl. border - border words), in
-    uint32 arithmetic.  Host restatement of offset_header_gathered_kernel (tests; the GPU path computes it in that kernel)."""
-    base = 0
-    for r in range(rank):
-        base = (base + (int(lengths[r]) & 0xFFFFFFFF) - int(borders[r])) & 0xFFFFFFFF
+    """Global word offset of shard `rank`'s body: sum over lower ranks of (words written incl. border - border words).  Host
+    restatement of offset_header_gathered_kernel (tests; the GPU path computes it in that kernel): like the kernel it sums ALL
+    shards without wrapping and refuses (OverflowError; the kernel: error-word bit) a plan whose hypercube runs exceed the
+    format's 32-bit offsets -- on every rank alike."""
+    base = total = 0
+    for r in range(len(lengths)):
+        if r == rank:
+            base = total
+        total += (int(lengths[r]) & 0xFFFFFFFF) - int(borders[r])
+    if total > INDEX_MAX:
+        raise OverflowError(f"the hypercube runs of the {len(lengths)} shards add up to {total} words: more than the stream format's 32-bit offsets address")
     return base
+
+
+def check_global_extent(dtype, extent: Sequence[int]) -> None:
+    """What the stream format can carry at all (uint32 element count; uint32 offsets even if nothing compresses): ValueError otherwise.
+    Eight legal slabs (each < 2^32 elements) can form a global array that is not."""
+    import numpy as np
+
+    import ndzip_amd
+
+    n = 1
+    for x in extent:
+        n *= int(x)
+    if n > INDEX_MAX:
+        raise ValueError(f"extent {tuple(extent)} has {n} elements: more than index_type (uint32) counts")
+    bound_words = ndzip_amd.compressed_length_bound(dtype, tuple(int(x) for x in extent))  # (in words of the profile)
+    if bound_words > INDEX_MAX:
+        raise ValueError(f"extent {tuple(extent)}: compressed_length_bound = {bound_words} words does not fit the format's 32-bit offsets")
 
 
 class ShardedCodec:
@@ -120,6 +146,7 @@ class ShardedCodec:
 
         self.np_dtype = np.dtype(dtype)
         self.extent = tuple(int(x) for x in global_extent)
+        check_global_extent(self.np_dtype, self.extent)
         self.dims = len(self.extent)
         self.rank, self.world, self.group = rank, world, group
         # True leaves the header all-gather in flight behind decompress (off until it has run on a multi-GPU node; the
@@ -164,7 +191,7 @@ class ShardedCodec:
     def globalise(self) -> None:
         """lens_all (every rank's body_len) -> header_local holds GLOBAL offsets, base32 this rank's base."""
         self.compressor.offset_header_gathered(self.header_local, self.shard.num_hypercubes, self.lens_all, self.borders, self.rank,
-                                               self.base32)
+                                               self.world, self.base32)
 
     def finish(self) -> None:
         """Wait (stream-wise) for the header all-gather of the last compress()."""

@@ -72,6 +72,30 @@ def test_port_leg_is_well_formed():
     grid = synth_numpy((128, 128), np.float64, seed=2, noise_mask=0xFF)
     leg = bench.cpu_port_openmp(grid, 2, budget_s=0.5)
     _check_leg(leg, "port")
+    s = bench.cpu_port_serial(grid, "test sample")
+    _check_leg(s, "port")
+    assert s["cores"] == 1 and 0 < s["ratio"] < 1.1 and s["roundtrip_ok"]
+
+
+def test_configs0_has_a_cpu_line_without_the_compiled_reference(monkeypatch):
+    """oracle/_ref does not reach every box (it is built from /root/reference): BASELINE configs[0] -- 1D float32 16 Mi, one CPU
+    thread -- then still gets its line, timed on the C restatement and labelled as such"""
+    monkeypatch.setattr(oracle, "have_ref", lambda: False)
+    monkeypatch.setattr(bench, "cpu_port_openmp", lambda grid, cores, budget: {"value": 1.0, "unit": "GB/s", "cores": cores, "kind": "port", "sample": "stub"})
+    real = bench.cpu_port_serial
+    seen = {}
+
+    def small(sample, what):  # (the 64 MiB array is what bench times on the box; the contract is checked on its first 64 Ki elements)
+        seen["shape"], seen["dtype"] = sample.shape, sample.dtype
+        return real(sample[: 1 << 16], what)
+
+    monkeypatch.setattr(bench, "cpu_port_serial", small)
+    legs = bench.cpu_legs(synth_numpy((16, 16, 16), np.float32, seed=1, noise_mask=0xFF), 0.2)
+    assert seen == {"shape": (1 << 24,), "dtype": np.float32}
+    assert legs["cpu_baseline"]["kind"] == "port" and legs["cpu_baseline"]["why_kind"].startswith("kind=port")
+    leg = legs["cpu_port_serial_cfg1"]
+    _check_leg(leg, "port")
+    assert leg["cores"] == 1 and "configs[0]" in leg["sample"] and "cpu_reference_serial_cfg1" not in legs
 
 
 class _HostAccelerator:

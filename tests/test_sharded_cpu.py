@@ -184,3 +184,78 @@ def test_cfg4_plan_for_eight_ranks():
     # cfg5 (3D float64 1024^3 x8, decompress-only): 128 planes = 32 768 hypercubes per rank
     s5 = plan_shards((1024, 1024, 1024), 8)
     assert all(s.extent == (128, 1024, 1024) and s.num_hypercubes == 32768 for s in s5)
+
+
+def test_plans_the_format_cannot_carry_are_refused_on_the_host():
+    """index_type = uint32 (include/ndzip/ndzip.hh:20) counts elements and addresses stream words: eight legal slabs can form a
+    global array that is not legal.  ShardedCodec refuses such an extent before anything is allocated; the host restatement of the
+    offset kernel refuses lengths that add up past 2^32 - 1 on every rank, not only on the ranks whose own base overflows."""
+    from ndzip_amd.sharded import ShardedCodec, base_from_lengths, check_global_extent
+
+    check_global_extent(np.float64, (2048, 1024, 1024))           # bench.py --config 16gib: 2^31 elements, bound 2.2e9 words
+    check_global_extent(np.float32, (2048, 1024, 1024))           # cfg 4
+    with pytest.raises(ValueError, match="elements"):
+        check_global_extent(np.float32, (65536, 65536))           # 2^32 elements; each of 8 slabs (8192 x 65536) is fine by itself
+    check_global_extent(np.float32, (8192, 65536))
+    with pytest.raises(ValueError, match="32-bit offsets"):
+        check_global_extent(np.float32, (65536, 65536 - 64))      # countable, but incompressible data would not be addressable
+    with pytest.raises(ValueError):
+        ShardedCodec(np.float32, (65536, 65536), 0, 8, "cpu")     # (raises before any library call or allocation)
+    borders = [0, 0, 5]
+    assert base_from_lengths([0x7FFFFFFF, 0x7FFFFFFF, 6], borders, 2) == 0xFFFFFFFE
+    for rank in range(3):  # rank 0's own base is 0 and rank 1's fits: they must refuse all the same
+        with pytest.raises(OverflowError):
+            base_from_lengths([0xF0000000, 0x20000000, 5], borders, rank)
+
+
+def _overflow_rank_main(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from ndzip_amd import hip
+    from ndzip_amd.sharded import ShardedCodec
+    from tests.wavesim import sim
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    extent, dtype = (96, 32, 32), np.float32
+    full = synth_numpy(extent, dtype, seed=5, noise_mask=0xFF)
+    with sim.active():
+        codec = ShardedCodec(dtype, extent, rank, world, torch.device("cpu"))
+        sh = codec.shard
+        local = torch.from_numpy(np.ascontiguousarray(full[sh.start0: sh.start0 + sh.extent[0]]))
+        codec.compress(local)
+        codec.check()  # a plan that fits: clean
+        base_ok = int(codec.base32.numpy().view(np.uint32)[0])
+        # every rank's all-gathered lengths forged alike (what eight 4-GiB-class slabs of incompressible data would exchange)
+        codec.lens_all.copy_(torch.from_numpy(np.array([0xF0000000, 0x20000000, 7][:world], dtype=np.uint32).view(np.int32)))
+        codec.globalise()
+        message = ""
+        try:
+            codec.check()
+        except hip.NdzipHipError as e:
+            message = str(e)
+        codec.compress(local)  # the error word was cleared by check(): the handle works again
+        codec.check()
+        again = int(codec.base32.numpy().view(np.uint32)[0])
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{base_ok}\n{again}\n{message}\n")
+    dist.destroy_process_group()
+
+
+def test_overflowing_offsets_raise_on_every_rank_on_the_model_over_gloo(tmp_path):
+    """offset_header_gathered_kernel sums the all-gathered lengths of ALL shards in 64 bits: a plan whose hypercube runs exceed the
+    format's 32-bit offsets sets the error-word bit on every rank (rank 0, whose own base is 0, included), ShardedCodec.check()
+    raises there, and the handle is usable afterwards."""
+    import torch.multiprocessing as mp
+
+    from tests.wavesim import build as simbuild
+
+    simbuild.build()
+    world, port = 3, _free_port()
+    mp.spawn(_overflow_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        base_ok, again, message = (tmp_path / f"rank{r}.txt").read_text().split("\n")[:3]
+        assert base_ok == again and (r > 0) == (int(base_ok) > 0)
+        assert "32-bit offsets" in message and "0x4" in message, (r, message)
