@@ -876,7 +876,27 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
     }
 
     __syncthreads();  // every work-item has consumed the encoded run: overwrite `cube` with values
-    {
+    // Where the decoded values wait for the store pass.  1D / 2D and the 64-bit profiles: lds_layout (16 bytes of padding per 32
+    // values).  3D f32: UNPADDED 128-byte rows -- row t = the 32 values of work-item t -- with the 16-byte slot s of row r kept at
+    // slot s ^ (r & 7) (region-relative: `cube` need not be 128-byte aligned; the same idea as wide::value_layout).  The padded
+    // layout cost the store pass below a 2-way conflict on every read: its half-wavefront (y = 4 m .. 4 m + 3, 8 bytes per lane) spans
+    // 272 bytes, 16 more than the 64 banks hold (tools/lds_profile.py: 2.00x, 64 of ~1 000 LDS cycles per hypercube).  Here the
+    // four rows-of-the-cube of a half-wavefront are two adjacent 128-byte LDS rows, every slot of both touched exactly once (1.00x);
+    // the writer's 8 consecutive lanes put slot i at i ^ 0..7 of 8 different rows (1.00x as before).  Cost: one v_xad_u32 per
+    // 16-byte write for the slot (8 per work-item); the reader keeps one per-lane address and the plane in the offset field,
+    // because a plane is 8 rows and r & 7 does not depend on z.
+    constexpr bool swizzled_rows = Dims == 3 && sizeof(W) == 4;
+    if constexpr (swizzled_rows) {
+        char *row = cube + 128u * static_cast<uint32_t>(t);
+        const uint32_t key = (static_cast<uint32_t>(t) & 7u) * 16u;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) {
+            vec16 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v.w[j] = static_cast<uint32_t>(r[4 * i + j]);
+            lds_write16(row + (key ^ (16u * i)), v);
+        }
+    } else {
         char *own = cube + L::off(static_cast<uint32_t>(t) * 32u);
         write_run16<W>(own, *reinterpret_cast<W(*)[16]>(&r[0]));
         write_run16<W>(own + 16 * sizeof(W), *reinterpret_cast<W(*)[16]>(&r[16]));
@@ -949,8 +969,10 @@ NDZIP_DEV void inverse_transform_hypercube(typename profile<T, Dims>::word (&r)[
         const uint32_t lane_bytes = (y * static_cast<uint32_t>(gg.stride[1]) + 2 * xp) * static_cast<uint32_t>(sizeof(W));
         const uint64_t plane_step = gg.stride[0] * sizeof(W);
         char *dst = reinterpret_cast<char *>(scalar_pointer(out + origin));
-        const char *src = cube + L::off(y * 16 + 2 * xp);
-        constexpr uint32_t plane_bytes = L::off(256);
+        // f32: values (z, y, 2 xp .. 2 xp + 1) = row 8 z + y / 2 of the swizzled layout above, slot 4 (y & 1) + xp / 2, half xp & 1
+        const char *src = swizzled_rows ? cube + 128u * (y >> 1) + ((((y & 1u) * 4u + (xp >> 1)) ^ (y >> 1)) * 16u) + (xp & 1u) * 8u
+                                        : cube + L::off(y * 16 + 2 * xp);
+        constexpr uint32_t plane_bytes = swizzled_rows ? 8u * 128u : L::off(256);
         if constexpr (sizeof(W) == 4) {
 #pragma unroll
             for (uint32_t z = 0; z < 16; ++z) {
