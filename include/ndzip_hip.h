@@ -83,7 +83,11 @@ NDZIP_HIP_API int ndzip_hip_compressor_create(
  * Pure stream work: one kernel (two with a border), no allocation, no host synchronisation and no per-call state on the host
  * (what one launch hands to the next on the handle's scratch -- ticket counters, the tile descriptors' epoch -- is kept and
  * advanced on the device).  A call may therefore be recorded into a hipGraph and replayed on new data in the same buffers
- * (tests/test_hip_graph.py); the same holds for the decompress entry points, which keep no state at all. */
+ * (tests/test_hip_graph.py); the same holds for the decompress entry points, which keep no state at all.
+ * Before a capture: make ONE identical un-captured call (same extent, same pointer alignment).  The first launch of each kernel
+ * variant on a device (aligned / element-aligned pointers, paired / unpaired tiles) resolves its occupancy and function
+ * attributes through the runtime and caches them in the library; and what a capture records -- kernel variant, grid size -- is
+ * chosen from the extent and the pointers' alignment, so a replay is valid for buffers of the same extent and alignment only. */
 NDZIP_HIP_API int ndzip_hip_compressor_compress(ndzip_hip_compressor *c, const void *d_in, int dims, const uint32_t *extent,
         void *d_stream, uint32_t *d_stream_length_words);
 

@@ -29,6 +29,10 @@ NDZIP_HIP_API const char *ndzip_hip_stages_last_error(void);
 NDZIP_HIP_API int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in,
         void *d_out, uint32_t *d_out_len, uint32_t n, void *hip_stream);
 
+/* byte offset of the launch-epoch word inside a compressor's scratch (ndzip_amd/csrc/codec_launch.hpp: epoch_word); for the
+ * white-box test of the epoch's wrap-around */
+NDZIP_HIP_API uint32_t ndzip_hip_debug_scratch_epoch_offset(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,10 @@ extern "C" {
 
 const char *ndzip_hip_stages_last_error(void) { return g_last_error.c_str(); }
 
+// where the launch epoch sits in a compressor's scratch (codec_launch.hpp: 16 reserved descriptors, then the ticket lines) -- so that
+// a white-box test pokes the word the kernels read, whatever the layout constants are
+uint32_t ndzip_hip_debug_scratch_epoch_offset(void) { return 16u * static_cast<uint32_t>(sizeof(tile_desc)) + epoch_word * 4u; }
+
 int ndzip_hip_debug_stage(int stage, int dtype, int dims, const uint32_t *extent, uint32_t hc, const void *d_in, void *d_out,
         uint32_t *d_out_len, uint32_t n, void *hip_stream) {
     if (!valid_dtype(dtype) || !valid_dims(dims)) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "invalid argument");

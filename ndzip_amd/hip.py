@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_chunked_decompress",
 )
 # include/ndzip_hip_stages.h: the parity tests' stage entry point lives in a library of its own (the product library holds no stage kernel)
-STAGE_SYMBOLS = ("ndzip_hip_stages_last_error", "ndzip_hip_debug_stage")
+STAGE_SYMBOLS = ("ndzip_hip_stages_last_error", "ndzip_hip_debug_stage", "ndzip_hip_debug_scratch_epoch_offset")
 
 
 class NdzipHipError(RuntimeError):
@@ -114,6 +114,8 @@ def _bind_stages(L):
     L.ndzip_hip_stages_last_error.argtypes = []
     L.ndzip_hip_debug_stage.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ndzip_hip_debug_stage.restype = C.c_int
+    L.ndzip_hip_debug_scratch_epoch_offset.argtypes = []
+    L.ndzip_hip_debug_scratch_epoch_offset.restype = C.c_uint32
     return L
 
 

@@ -206,11 +206,13 @@ def test_launch_epoch_lives_in_the_scratch_and_starts_over(dtype, shapes):
     with sim.active(cus=3, blocks_per_cu=2):
         comp = hip.make_hip_compressor(dtype, hip.CompressorRequirements(*shapes))
         # (white box, model only -- its "device memory" is the heap: the handle's scratch pointer sits behind {int, int, uint32, stream},
-        # the epoch word 16 reserved descriptors + (16 ticket lines + the 'done' line) x 128 bytes into the scratch)
+        # the epoch word where the library's own layout constants put it: ndzip_hip_debug_scratch_epoch_offset, a stage hook)
         import ctypes
 
         scratch = ctypes.c_uint64.from_address(comp._h.value + 24).value
-        epoch_word = ctypes.c_uint32.from_address(scratch + 16 * 8 + 17 * 128)
+        offset = hip.stages_lib().ndzip_hip_debug_scratch_epoch_offset()
+        assert offset == 16 * 8 + 17 * 128  # (today's layout: 16 reserved descriptors, 16 ticket lines + the 'done' line)
+        epoch_word = ctypes.c_uint32.from_address(scratch + offset)
         assert epoch_word.value == 1  # (a fresh handle)
         epoch_word.value = (1 << 30) - 2
         expected = [(1 << 30) - 2, (1 << 30) - 1, 1, 2, 3, 4, 5, 6]
