@@ -35,7 +35,7 @@ def test_stage_hooks_live_in_a_library_of_their_own():
     """include/ndzip_hip_stages.h (the parity tests' single-hypercube stage entry point) is exported by libndzip_hip_stages.so and by
     nothing else: the product library holds neither the entry point nor a stage kernel."""
     declared = _declared_symbols("ndzip_hip_stages.h")
-    assert sorted(hip.STAGE_SYMBOLS) == declared == ["ndzip_hip_debug_stage", "ndzip_hip_stages_last_error"]
+    assert sorted(hip.STAGE_SYMBOLS) == declared == ["ndzip_hip_debug_scratch_epoch_offset", "ndzip_hip_debug_stage", "ndzip_hip_stages_last_error"]
     out = subprocess.run(["nm", "-D", "--defined-only", hip.STAGES_LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert set(re.findall(r" T (ndzip_hip_\w+)", out)) == set(declared)
     S = hip.stages_lib()
