@@ -243,6 +243,30 @@ struct coding<uint64_t> {
         const int q = t & 3;
         const uint32_t c = static_cast<uint32_t>(t) >> 2;
         if (q < 2) *R::ptr(run32 + 2 * c + (q == 0 ? 1u : 0u)) = h.head_word;
+        // Dense wavefront (every chunk of it keeps all 64 planes, at an even word position: incompressible data): the compaction
+        // below would store 32 dwords per lane at a lane stride of 256 bytes -- with the swizzle still an 8-way bank conflict on
+        // each of its 32 instructions.  Instead the two lanes that hold the halves of the same planes (t, t ^ 2: high / low
+        // dwords) trade halves -- the lower lane takes planes 0..15 of its 32, the upper one 16..31 -- and every lane writes its
+        // 16 whole 64-bit words as eight 16-byte stores (two DPP moves + two selects per word pair; compiled code, no assembly).
+        // Wave-uniform: one s_cmp on a ballot.  (What the f32 encoder's write_planes32 does per chunk.)
+        if (__ballot(h.head_bits != 0xffffffffu || ((h.slot >> 1) & 1u) != 0) == 0) {
+            const bool upper = (q & 2) != 0;
+            const uint32_t a = lds_address(run32) + 8u * ((h.slot >> 1) + (upper ? 16u : 0u));  // (linear; 16-byte aligned)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                vec16 v;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * k + e;
+                    const uint32_t others_first = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(planes[i]), 0x4e, 0xf, 0xf, true));
+                    const uint32_t others_second = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(planes[16 + i]), 0x4e, 0xf, 0xf, true));
+                    v.w[2 * e] = upper ? planes[16 + i] : others_first;       // low dword: lanes 2, 3 hold it
+                    v.w[2 * e + 1] = upper ? others_second : planes[i];       // high dword: lanes 0, 1 hold it
+                }
+                lds_write16(lds_pointer(R::at(a + 16u * static_cast<uint32_t>(k))), v);
+            }
+            return;
+        }
         // a running linear LDS address, one 64-bit stream word per kept plane; branch-free, EXEC-masked (gfx950_lds.hpp), with
         // run_layout's swizzle folded into the store address
         static_assert(R::at(0x3f8u) == (0x3f8u ^ 0x70u), "lds_append_flagged64 spells run_layout<uint64_t>::at out");

@@ -14,8 +14,9 @@ def test_lds_profile_of_a_small_grid():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     shares = {m.group(1): float(m.group(2)) for m in re.finditer(r"## (\w+): LDS-array cycles .* = ([\d.]+)% of the cycles", r.stdout)}
     assert set(shares) == {"compress", "decompress"}
-    # 3D f32 on the benchmark's synthetic data: conflicts are a fifth to a half of the LDS-array cycles (round-1 PMC: 35 / 40 %)
-    assert 10 < shares["compress"] < 45 and 25 < shares["decompress"] < 55, shares
+    # 3D f32 on the benchmark's synthetic data: conflicts are a fifth to a half of the LDS-array cycles (round-1 PMC: 35 / 40 %;
+    # round 5: the decoder's store pass reads conflict-free from swizzled rows, 27 -> 22 %: what is left is the gather)
+    assert 10 < shares["compress"] < 45 and 15 < shares["decompress"] < 55, shares
     # the compaction writes, by source line (the model's stand-in for the EXEC-masked store sequence, called from write_planes32)
     assert re.search(r"ds_write_b32\s+gfx950_lds\.hpp:\d+ <- codec_kernels\.hpp:\d+", r.stdout), r.stdout
     assert re.search(r"ds_read_b32\s+codec_kernels\.hpp:\d+", r.stdout)            # the decoder's gather
