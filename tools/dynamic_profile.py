@@ -46,6 +46,8 @@ def main():
 
     shape = tuple(int(x) for x in a.shape.split(","))
     dt = np.dtype(a.dtype).type
+    if dt == np.float64 and not a.f64_work_items:
+        a.f64_work_items = 128  # (the library's default; named explicitly, or the test helper would run every mapping for comparison)
     data = synth.synth_numpy(shape, dt, seed=1, noise_mask=a.noise_mask)
     want = oracle.compress(data)
     nhc = hip.num_hypercubes(shape)
