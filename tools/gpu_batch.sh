@@ -32,6 +32,14 @@ first)
   cat ${O}_smoke.txt
   (timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider --timeout 180 2>&1 | tail -120) > ${O}_gputest.txt
   tail -30 ${O}_gputest.txt
+  # a failing suite is bisected in the SAME call (calls are scarce): the product library and the build without inline assembly /
+  # scalar pins (_variants/plain.so) on the same cases, each 64-bit decoder kernel on its own
+  if grep -qE "[0-9]+ (failed|error)" ${O}_gputest.txt; then
+    for v in ndzip_amd/libndzip_hip.so ndzip_amd/_variants/plain.so; do
+      [ -f $v ] && (timeout 300 python tools/variant_parity.py $v 2>&1 | tail -40) >> ${O}_variant_parity.txt
+    done
+    cat ${O}_variant_parity.txt
+  fi
   TRAFFIC_KEY=float32-512x512x512 timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary.txt
   cp gpurun_out/traffic.json profiles/traffic.json 2>/dev/null
   timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
@@ -95,7 +103,7 @@ poll)
   ;;
 collect)
   dst=${3:-$tag}
-  for f in rocminfo smoke gputest bench_n1.json configs workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d \
+  for f in rocminfo smoke gputest variant_parity bench_n1.json configs workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d \
            rocprofv3_summary_f64_3d_decode_256 rocprofv3_summary_f64_3d_decode_128 ab_variants ab_variants_cfg1 ab_variants_f64_2d \
            ab_variants_f64_3d phase_timing two_process_stress; do
     for ext in "" .txt; do
