@@ -490,6 +490,14 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         }
         const uint32_t chunk_excl = ((wave & 1) ? static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[2 * grp]))) : 0u) + incl - count;
         if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
+        // The ticket the NEXT iteration reads behind its B1 (it needs one iff it has a tile), drawn here, by the lane that has just
+        // published: its round trip (~1 us under a streaming load) is over long before B3.  Rounds 1-4 drew it right behind B3 so
+        // that the copy-out would hide it -- but loads, stores and atomics retire through ONE in-order counter, and the first
+        // wait behind the copy-out (whatever it is for) then also waits for this atomic: in the executed stream of the built kernel
+        // wavefront 0 stood still for the rest of the round trip in front of its transposes, with the other three waiting at B4.
+        const bool draw = first_of_tile && next_tile < ntiles;
+        uint32_t ticket_after_next = 0;
+        if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         // late part of the prefetch: after the stencil, so these registers are not live across it (the previous
         // tile's planes are).  Both parts are unconditional (clamped index): a conditional load keeps the old registers
         // live around the whole loop.
@@ -525,15 +533,19 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
         }
         lds_append_complete();  // (the plane writes of write_planes32 are inline asm: the compiler's waitcnt insertion does not see them)
         __syncthreads();  // B3: previous tile's runs complete in LDS, its prefix known
-        // the ticket the NEXT iteration reads behind its B1 (it needs one iff it has a tile); in flight during the copy-out
-        const bool draw = first_of_tile && next_tile < ntiles;
-        uint32_t ticket_after_next = 0;
-        if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
             const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
             copy_out<W, C::threads>(reinterpret_cast<const W *>(tile_run), body + prefix, prev_aggregate, tid);
             if (prev_active && first_of_hc) header[prev_hc] = prefix + prev_run_start + prev_my_len;  // offset_after(hc), common.hh:342-347
         }
+        // The ticket drawn behind B3 is looked at only HERE, behind the transposes.  hipcc sinks the transposes of the current tile
+        // (register-only work, needed next iteration) behind the copy-out on its own -- and, left alone, hoists this conditional
+        // LDS store and the s_waitcnt vmcnt(0) in front of its atomic result above them, where a transpose temporary that shares
+        // the result's VGPR then makes EVERY wavefront wait for all of its outstanding memory operations: the copy-out's stores
+        // just issued and the late prefetch, with ~270 instructions of independent work right behind the wait (round 5, from the
+        // executed stream of the built kernel).  With the pin the transposes run while the stores are acknowledged and the
+        // atomic returns; the wait moves behind them.
+        registers_complete_here(planes);
         if (draw) misc[NW + 1] = ticket_after_next;
         __syncthreads();  // B4: copy-out has read the runs before the next tile is staged over them; next ticket in LDS
         have_prev = true;
@@ -666,6 +678,9 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         }
         chunk_excl += incl - count;
         if (first_of_tile) publish_aggregate(desc, tile, aggregate);  // as early as possible: successors wait on this
+        const bool draw = first_of_tile && next_tile < ntiles;  // the ticket the next iteration reads behind its B1: see compress_kernel_db
+        uint32_t ticket_after_next = 0;
+        if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         __builtin_amdgcn_sched_barrier(0);
         wide::load_regs<W, Dims, Aligned, 1, early_vectors>(in, gg, next_origin, t, pre);
         __builtin_amdgcn_sched_barrier(0);
@@ -680,14 +695,14 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
         }
         lds_append_complete();  // (E::write's plane stores are inline asm: the compiler's waitcnt insertion does not see them)
         __syncthreads();  // B3: previous tile's run complete in LDS, its prefix known
-        const bool draw = first_of_tile && next_tile < ntiles;  // the ticket the next iteration reads behind its B1
-        uint32_t ticket_after_next = 0;
-        if (draw) ticket_after_next = atomicAdd(ticket_counter, 1u);
         if (have_prev) {
             const uint32_t prefix = static_cast<uint32_t>(wave_uniform(static_cast<int>(misc[NW])));
             copy_out<W, C::threads>(reinterpret_cast<const W *>(smem), body + prefix, prev_aggregate, tid);
             if (first_of_tile) header[prev_tile] = prefix + prev_aggregate;  // offset_after(hc), common.hh:342-347
         }
+        // (the ticket is looked at behind the transposes, which hipcc sinks behind the copy-out: see compress_kernel_db)
+        static_assert(E::planes_per_lane == 32, "registers_complete_here takes the 32 plane registers");
+        registers_complete_here(planes);
         if (draw) misc[NW + 1] = ticket_after_next;
         __syncthreads();  // B4: copy-out has read the run before the next tile is staged over it; next ticket in LDS
         have_prev = true;

@@ -120,6 +120,17 @@ NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&w)[32]) {
             "+v"(w[24]), "+v"(w[25]), "+v"(w[26]), "+v"(w[27]), "+v"(w[28]), "+v"(w[29]), "+v"(w[30]), "+v"(w[31])::"memory");
 }
 
+// Ordering pin for 32 register values: everything that computes w[0 .. 32) comes before this point, no memory access of the
+// program crosses it (the "memory" clobber), nothing is emitted.  Used where the compiler's own placement put a wait for ALL
+// outstanding vector-memory operations in front of a long stretch of register-only work (compress kernels: the 32x32 transposes
+// behind the copy-out's stores; see codec_launch.inl).  Two statements: an asm takes at most 30 operands.
+NDZIP_DEV void registers_complete_here(uint32_t (&w)[32]) {
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]),
+            "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15])::"memory");
+    asm volatile("" : "+v"(w[16]), "+v"(w[17]), "+v"(w[18]), "+v"(w[19]), "+v"(w[20]), "+v"(w[21]), "+v"(w[22]), "+v"(w[23]),
+            "+v"(w[24]), "+v"(w[25]), "+v"(w[26]), "+v"(w[27]), "+v"(w[28]), "+v"(w[29]), "+v"(w[30]), "+v"(w[31])::"memory");
+}
+
 // The value, as far as the optimiser is concerned, from nowhere: stops hipcc from rewriting `p + 8 * (x << i >> 31)` into
 // bfe(4 bits) / and -8 / add (three instructions) where v_bfe_i32 + v_lshl_add_u32 (two) do, and lets the 0 / -1 mask be
 // reused for the select afterwards.

@@ -60,6 +60,8 @@ NDZIP_DEV void lds_reads_issued_before_use(uint32_t (&)[32]) {}  // (instruction
 
 NDZIP_DEV int32_t opaque_vgpr(int32_t x) { return x; }
 
+NDZIP_DEV void registers_complete_here(uint32_t (&)[32]) {}  // (instruction placement only)
+
 NDZIP_DEV void wait_for_own_memory_operations() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 NDZIP_DEV uint32_t exchange_performed(uint32_t *p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
