@@ -50,11 +50,13 @@ first)
 explain)
   # variants present in ndzip_amd/_variants/ decide the A/B legs:
   #   r04 / r03 / r02 = the library at the end of that round; plainloads = HEAD without the nt input loads; plain = HEAD without inline asm
+  #   r05a = HEAD before round 5's change of the post-B3 order (ticket drawn behind B3, full memory drain in front of the transposes);
+  #   trearly = the transposes pinned in front of the look-back and B3 (round 1's measured order) instead of overlapping the copy-out's stores;
   #   winpub = look-back window read a third of an iteration later, still ahead of the late prefetch (DESIGN section 5 candidate 2);
   #   wg3 = HEAD held to 3 wavefronts per SIMD (f32 kernels): what the 4th workgroup per CU buys.   All checked bit-exact on the CPU
   #   beforehand (tools/variant_parity_cpu.py).  (A 128-work-item f32 tile -- two independent 2-wavefront pipelines -- is NOT rebuilt:
   #   round 1 measured one hypercube per 128-thread workgroup at 0.437 ms against 0.20: twice the tickets, descriptors, look-backs.)
-  V="main"; for v in winpub wg3 r04 r03 r02 plainloads plain; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
+  V="main"; for v in r05a trearly winpub wg3 r04 r03 r02 plainloads plain; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
   (timeout 700 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt; cat ${O}_ab_variants.txt
   (timeout 400 bash tools/ab.sh "$V" --config 1 2>&1) > ${O}_ab_variants_cfg1.txt
   for w in 0 3 2 1; do echo -n "workgroups per CU $w: "; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compress-only --workgroups-per-cu $w 2>/dev/null | tail -1 | frac_line; done > ${O}_workgroups_per_cu.txt 2>&1
