@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""EXECUTED order of barriers, vector-memory operations and s_waitcnt vmcnt of ONE wavefront of a compress kernel, one iteration of
+its persistent loop (CPU; test tooling: the built gfx950 code object on tests/gfx950_exec.py with a trace hook).  A listing's block
+order is not execution order, and where hipcc places a wait -- or sinks a stretch of register-only work -- decides what a wavefront
+overlaps with what; round 5 found a full memory drain in front of ~270 independent instructions this way.
+Each line: +instructions executed since the previous line, address, instruction.
+usage: exec_trace.py [--wave 0] [--f64] [--lib ndzip_amd/_variants/<name>.so] [--lgkm]"""
+import argparse
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--wave", type=int, default=0)
+    ap.add_argument("--f64", action="store_true")
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--lgkm", action="store_true", help="also list s_waitcnt lgkmcnt and LDS barriers' neighbours")
+    a = ap.parse_args()
+    from ndzip_amd import hip
+    from ndzip_amd.synth import synth_numpy
+    from oracle import oracle
+    from tests import gfx950_exec as gx
+    from tests.wavesim import build as simbuild
+    from tests.wavesim import sim
+
+    named = gx.Bridge.kernel_named
+
+    def with_lab_suffix(self, host_name):  # (lab builds: the kernels take one more uint32, ignored unless built for ablation)
+        k = named(self, host_name)
+        return k if k is not None else named(self, host_name + "j")
+
+    gx.Bridge.kernel_named = with_lab_suffix
+    log, count = [], [0]
+
+    def trace(w, ins):
+        if w.wg.index != 0 or w.index != a.wave:
+            return
+        count[0] += 1
+        op = ins.op
+        if op.startswith(("global_", "s_barrier", "s_sleep")) or (op == "s_waitcnt" and ("vmcnt" in ins.text or a.lgkm)):
+            log.append((count[0], ins.addr, ins.text.strip()[:100]))
+
+    b = gx.Bridge(simbuild.build(), [os.path.abspath(a.lib) if a.lib else hip.LIB_PATH], tempfile.mkdtemp(prefix="gfxtrace"))
+    b.trace = trace
+    b.only = ["compress_kernel_wide" if a.f64 else "compress_kernel_db"]
+    data = synth_numpy((64, 64, 64), np.float64, seed=1, noise_mask=0xFF) if a.f64 else synth_numpy((64, 64, 128), np.float32, seed=1, noise_mask=0xFF)
+    with b:
+        got = sim.compress(data, cus=2, blocks_per_cu=2)  # 4 workgroups, 16 tiles each
+    assert np.array_equal(got, oracle.compress(data))
+    bars = [i for i, l in enumerate(log) if "s_barrier" in l[2]]
+    start, end = bars[1 + 4 * 2], bars[1 + 4 * 3]  # the prologue's barrier and two iterations skipped; four barriers per iteration
+    prev = log[start][0]
+    for n, addr, text in log[start:end + 1]:
+        print(f"+{n - prev:5d}  {addr:#07x}  {text}")
+        prev = n
+
+
+if __name__ == "__main__":
+    main()
