@@ -394,13 +394,15 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
     // Tickets.  The ticket of the tile an iteration works on was drawn a little more than one iteration earlier: the one for
-    // the first tile here (its own LDS slot), the one for the second right behind it, every later one behind B3 of the
-    // iteration before -- i.e. just before that iteration's copy-out, which hides the atomic's round trip (~1 us under a
-    // streaming load, MI355X guide "dequeue").  Drawn at the top of the iteration that consumes it behind B1 -- as round 1 had
-    // it -- that round trip sat on wavefront 0's path to B1 and with it on the whole workgroup's (built without LLVM's atomic
-    // optimizer: it turns the single-lane atomicAdd into mbcnt + atomic + readfirstlane and waits for the result at once).
-    // A whole extra tile of look-ahead was measured in round 1 and loses (0.255 vs 0.205 ms: claim order and processing order
-    // drift apart and the look-back waits); this is a quarter of an iteration.
+    // the first tile here (its own LDS slot), the one for the second right behind it, every later one in the iteration before,
+    // next to the aggregate's publish (behind B2) -- its round trip (~1 us under a streaming load, MI355X guide "dequeue") is
+    // over by B3, and its result is looked at only behind the copy-out and the transposes.  Drawn at the top of the iteration
+    // that consumes it behind B1 -- as round 1 had it -- that round trip sat on wavefront 0's path to B1 and with it on the
+    // whole workgroup's (built without LLVM's atomic optimizer: it turns the single-lane atomicAdd into mbcnt + atomic +
+    // readfirstlane and waits for the result at once); drawn behind B3 (rounds 2-4) it sat, through the one in-order memory
+    // counter, in the first wait behind the copy-out's stores.  A whole extra tile of look-ahead was measured in round 1 and
+    // loses (0.255 vs 0.205 ms: claim order and processing order drift apart and the look-back waits); this is a third of an
+    // iteration.
     // (the first ticket's round trip is the first thing on the kernel's critical path: drawn before anything else, with the
     // zero block filled while it is in flight)
     uint32_t first_ticket = 0;
@@ -624,7 +626,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
     const uint32_t cls = blockIdx.x % num_classes;
     uint32_t *ticket_counter = tickets + cls * ticket_stride_words;
     // tickets: see compress_kernel_db (first one in its own slot -- drawn first of all, the zero block is filled while it is in
-    // flight --, every later one drawn behind the B3 before its consumer's B1)
+    // flight --, every later one drawn next to the publish of the iteration before its consumer's B1)
     uint32_t first_ticket = 0;
     if (tid == 0) first_ticket = atomicAdd(ticket_counter, 1u);
     for (uint32_t i = tid; i < L::zero_bytes / 4; i += C::threads) reinterpret_cast<uint32_t *>(zero_region)[i] = 0;

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--f64", action="store_true")
     ap.add_argument("--lib", default=None)
     ap.add_argument("--lgkm", action="store_true", help="also list s_waitcnt lgkmcnt and LDS barriers' neighbours")
+    ap.add_argument("--decompress", action="store_true", help="a decompress kernel instead (one workgroup start to end)")
+    ap.add_argument("--f64-work-items", type=int, default=0)
     a = ap.parse_args()
     from ndzip_amd import hip
     from ndzip_amd.synth import synth_numpy
@@ -49,8 +51,18 @@ def main():
 
     b = gx.Bridge(simbuild.build(), [os.path.abspath(a.lib) if a.lib else hip.LIB_PATH], tempfile.mkdtemp(prefix="gfxtrace"))
     b.trace = trace
-    b.only = ["compress_kernel_wide" if a.f64 else "compress_kernel_db"]
+    b.only = ["decompress_kernel"] if a.decompress else ["compress_kernel_wide" if a.f64 else "compress_kernel_db"]
     data = synth_numpy((64, 64, 64), np.float64, seed=1, noise_mask=0xFF) if a.f64 else synth_numpy((64, 64, 128), np.float32, seed=1, noise_mask=0xFF)
+    if a.decompress:
+        with b:
+            back = sim.decompress(oracle.compress(data), data.dtype, data.shape, f64_work_items=a.f64_work_items or (128 if a.f64 else 0))
+        assert np.array_equal(back.view(np.uint8), data.view(np.uint8))
+        prev = 0
+        for n, addr, text in log:
+            print(f"+{n - prev:5d}  {addr:#07x}  {text}")
+            prev = n
+        print(f"+{count[0] - prev:5d}  (end)")
+        return
     with b:
         got = sim.compress(data, cus=2, blocks_per_cu=2)  # 4 workgroups, 16 tiles each
     assert np.array_equal(got, oracle.compress(data))
