@@ -126,7 +126,11 @@ def _model_rank_main(rank, world, port, extent, dtype_name, out_dir, async_gathe
 
 @pytest.mark.parametrize("extent,dtype,world,async_gather", [((64, 48, 32), np.float32, 2, False), ((130, 200), np.float64, 2, True),
                                                            ((50, 37, 41), np.float32, 2, False), ((6 * 4096 + 5,), np.float64, 3, True),
-                                                           ((96, 32, 32), np.float32, 3, False)])
+                                                           ((96, 32, 32), np.float32, 3, False),
+                                                           # eight ranks, the driver's SCALE shape in small: cfg 4's plan (8 equal slabs, no border) ...
+                                                           ((128, 32, 32), np.float32, 8, True),
+                                                           # ... and eight unequal slabs of a 2D f64 grid with a border (the last rank takes the tail rows)
+                                                           ((64 * 11 + 5, 130), np.float64, 8, False)])
 def test_sharded_codec_on_the_model_over_gloo(tmp_path, extent, dtype, world, async_gather):
     import torch.multiprocessing as mp
 
