@@ -57,7 +57,9 @@ explain)
   #   beforehand (tools/variant_parity_cpu.py).  (A 128-work-item f32 tile -- two independent 2-wavefront pipelines -- is NOT rebuilt:
   #   round 1 measured one hypercube per 128-thread workgroup at 0.437 ms against 0.20: twice the tickets, descriptors, look-backs.)
   V="main"; for v in r05a trearly winpub wg3 r04 r03 r02 plainloads plain; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
-  (timeout 700 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt; cat ${O}_ab_variants.txt
+  # (both launch times: round 1 measured cache-policy hints moving time BETWEEN the two kernels -- nt input loads: compress 0.193 vs
+  # 0.20 ms alone, decompress +13 % in the full loop, profiles/r01_ablation_notes.txt -- so plainloads is judged on the pair)
+  (AB_MODE=both timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt; cat ${O}_ab_variants.txt
   (timeout 400 bash tools/ab.sh "$V" --config 1 2>&1) > ${O}_ab_variants_cfg1.txt
   for w in 0 3 2 1; do echo -n "workgroups per CU $w: "; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compress-only --workgroups-per-cu $w 2>/dev/null | tail -1 | frac_line; done > ${O}_workgroups_per_cu.txt 2>&1
   cat ${O}_workgroups_per_cu.txt
