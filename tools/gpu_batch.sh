@@ -28,6 +28,8 @@ frac_line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(
 case $stage in
 first)
   rocminfo | grep -E "gfx|Compute Unit" | head -4 > ${O}_rocminfo.txt
+  (timeout 20 rocm-smi --showclocks --showpower --showmemuse 2>&1 | grep -vE "^=|^$" | head -20) >> ${O}_rocminfo.txt  # (what the numbers were taken under)
+  python -c "from ndzip_amd.build import kernels_fingerprint as k; print('kernels_fingerprint', k())" >> ${O}_rocminfo.txt
   (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -8) > ${O}_smoke.txt
   cat ${O}_smoke.txt
   (timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider --timeout 180 2>&1 | tail -120) > ${O}_gputest.txt
