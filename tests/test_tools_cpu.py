@@ -51,3 +51,38 @@ def test_prof_summary_on_a_synthetic_rocprofv3_tree(tmp_path):
     assert entry["kernels"] == kernels_fingerprint()
     # FETCH_SIZE doubled (gfx950: wide coalesced reads are tallied at half their bytes), KiB units
     assert entry["compress_hbm_bytes_per_launch"] == int(265000.0 * 1024 * 2 + 362000.0 * 1024)
+
+
+def _trace(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exec_trace.py"), *args], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    import re
+
+    return [(int(m.group(1)), m.group(2)) for m in (re.match(r"\+\s*(\d+)\s+0x[0-9a-f]+\s+(.*)$", l) for l in r.stdout.splitlines()) if m]
+
+
+def test_no_memory_drain_between_the_copy_out_and_the_transposes():
+    """The order hipcc gives the tail of a compress iteration, from the EXECUTED stream of the built kernel (tools/exec_trace.py):
+    behind B3 the copy-out's stores are issued and the ~260 instructions of the transposes follow WITHOUT a wait for all outstanding
+    memory operations in between; the ticket atomic is not issued in that stretch (it was drawn behind B2).  Round 5 found both
+    wrong in the binary although the source suggested otherwise: this pins the property against the next
+    compiler release or an innocent-looking edit."""
+    for args, min_stores in (((), 3), (("--f64",), 3)):
+        ops = _trace(*args)
+        bars = [i for i, (_, t) in enumerate(ops) if t.startswith("s_barrier")]
+        assert len(bars) == 5, ops  # B1 (opening the iteration), B2, B3, B4, B1 of the next one
+        b2, b3, b4 = bars[1], bars[2], bars[3]
+        publish = [t for _, t in ops[b2:b3]]
+        assert any(t.startswith("global_atomic_add") for t in publish), publish  # the ticket: next to the publish ...
+        tail = ops[b3 + 1:b4]
+        assert not any(t.startswith("global_atomic") for _, t in tail), tail      # ... not behind B3
+        stores = [i for i, (_, t) in enumerate(tail) if t.startswith("global_store")]
+        assert len(stores) >= min_stores, tail
+        after = tail[stores[-1] + 1:]
+        # what follows the last store: at most partial waits, then a stretch of >= 100 instructions (the transposes) before any vmcnt(0)
+        executed = 0
+        for gap, text in after:
+            executed += gap
+            if "vmcnt(0)" in text:
+                break
+        assert executed >= 100, (args, after)
