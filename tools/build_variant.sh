@@ -7,6 +7,7 @@
 #   -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION     NDZIP_HIP_EXP / NDZIP_HIP_BPC / NDZIP_HIP_NO_PAIRED (tools/ablate.sh)
 #   -DNDZIP_EXP_PHASE_TIMING                   per-phase cycle counters of the f32 compress iteration (NDZIP_HIP_EXP=16)
 #   -DNDZIP_EXP_WINDOW_BEHIND_PUBLISH, -DNDZIP_EXP_TRANSPOSE_BEFORE_LOOKBACK, -DNDZIP_EXP_EARLY_VECTORS=n, -DNDZIP_EXP_DB_WAVES=n
+#   -DNDZIP_EXP_COPYOUT_BATCH=n                copy-out: the LDS reads of n vectors per work-item issued back to back, one wait, then the stores
 #   -DNDZIP_PLAIN_INPUT_LOADS                  default cache policy instead of nt for the read-once input
 #   -DNDZIP_EXP_LINEAR_RUN64                   64-bit encoded runs linear in LDS (round-1 layout) instead of XOR-swizzled
 # e.g. tools/build_variant.sh knobs --lab -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION

@@ -54,11 +54,13 @@ explain)
   #   r04 / r03 / r02 = the library at the end of that round; plainloads = HEAD without the nt input loads; plain = HEAD without inline asm
   #   r05a = HEAD before round 5's change of the post-B3 order (ticket drawn behind B3, full memory drain in front of the transposes);
   #   trearly = the transposes pinned in front of the look-back and B3 (round 1's measured order) instead of overlapping the copy-out's stores;
+  #   cobatch2 = copy-out with the LDS reads of two vectors per work-item in flight before the first store (five serial LDS round trips per
+  #   wavefront become three; four at a time spill at 128 VGPRs -- what round 1's "unrolled x3: 0.249 vs 0.240" was);
   #   winpub = look-back window read a third of an iteration later, still ahead of the late prefetch (DESIGN section 5 candidate 2);
   #   wg3 = HEAD held to 3 wavefronts per SIMD (f32 kernels): what the 4th workgroup per CU buys.   All checked bit-exact on the CPU
   #   beforehand (tools/variant_parity_cpu.py).  (A 128-work-item f32 tile -- two independent 2-wavefront pipelines -- is NOT rebuilt:
   #   round 1 measured one hypercube per 128-thread workgroup at 0.437 ms against 0.20: twice the tickets, descriptors, look-backs.)
-  V="main"; for v in r05a trearly winpub wg3 r04 r03 r02 plainloads plain; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
+  V="main"; for v in r05a trearly cobatch2 winpub wg3 r04 r03 r02 plainloads plain; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
   # (both launch times: round 1 measured cache-policy hints moving time BETWEEN the two kernels -- nt input loads: compress 0.193 vs
   # 0.20 ms alone, decompress +13 % in the full loop, profiles/r01_ablation_notes.txt -- so plainloads is judged on the pair)
   (AB_MODE=both timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt; cat ${O}_ab_variants.txt
