@@ -67,7 +67,7 @@ def test_no_memory_drain_between_the_copy_out_and_the_transposes():
     memory operations in between; the ticket atomic is not issued in that stretch (it was drawn behind B2).  Round 5 found both
     wrong in the binary although the source suggested otherwise: this pins the property against the next
     compiler release or an innocent-looking edit."""
-    for args, min_stores in (((), 3), (("--f64",), 3)):
+    for args, min_stores in (((), 3), (("--f64",), 3), (("--f64", "--dims", "2"), 3), (("--dims", "1"), 3)):  # cfg 2, 3D f64, cfg 3, cfg 1
         ops = _trace(*args)
         bars = [i for i, (_, t) in enumerate(ops) if t.startswith("s_barrier")]
         assert len(bars) == 5, ops  # B1 (opening the iteration), B2, B3, B4, B1 of the next one

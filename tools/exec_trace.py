@@ -4,7 +4,7 @@ its persistent loop (CPU; test tooling: the built gfx950 code object on tests/gf
 order is not execution order, and where hipcc places a wait -- or sinks a stretch of register-only work -- decides what a wavefront
 overlaps with what; round 5 found a full memory drain in front of ~270 independent instructions this way.
 Each line: +instructions executed since the previous line, address, instruction.
-usage: exec_trace.py [--wave 0] [--f64] [--lib ndzip_amd/_variants/<name>.so] [--lgkm]"""
+usage: exec_trace.py [--wave 0] [--f64] [--dims 3] [--decompress] [--lib ndzip_amd/_variants/<name>.so] [--lgkm]"""
 import argparse
 import os
 import sys
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--lgkm", action="store_true", help="also list s_waitcnt lgkmcnt and LDS barriers' neighbours")
     ap.add_argument("--decompress", action="store_true", help="a decompress kernel instead (one workgroup start to end)")
     ap.add_argument("--f64-work-items", type=int, default=0)
+    ap.add_argument("--dims", type=int, default=3, choices=[1, 2, 3])
     a = ap.parse_args()
     from ndzip_amd import hip
     from ndzip_amd.synth import synth_numpy
@@ -52,7 +53,9 @@ def main():
     b = gx.Bridge(simbuild.build(), [os.path.abspath(a.lib) if a.lib else hip.LIB_PATH], tempfile.mkdtemp(prefix="gfxtrace"))
     b.trace = trace
     b.only = ["decompress_kernel"] if a.decompress else ["compress_kernel_wide" if a.f64 else "compress_kernel_db"]
-    data = synth_numpy((64, 64, 64), np.float64, seed=1, noise_mask=0xFF) if a.f64 else synth_numpy((64, 64, 128), np.float32, seed=1, noise_mask=0xFF)
+    # 64 tiles: 128 f32 hypercubes (two per tile) / 64 f64 hypercubes
+    shape = {3: (64, 64, 128), 2: (512, 1024), 1: (128 * 4096,)}[a.dims] if not a.f64 else {3: (64, 64, 64), 2: (512, 512), 1: (64 * 4096,)}[a.dims]
+    data = synth_numpy(shape, np.float64 if a.f64 else np.float32, seed=1, noise_mask=0xFF)
     if a.decompress:
         with b:
             back = sim.decompress(oracle.compress(data), data.dtype, data.shape, f64_work_items=a.f64_work_items or (128 if a.f64 else 0))
