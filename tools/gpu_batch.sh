@@ -48,6 +48,12 @@ first)
   cat ${O}_bench_n1.json; tail -5 ${O}_bench_n1.err
   (timeout 700 bash tools/bench_configs.sh 2>&1) > ${O}_configs.txt
   cat ${O}_configs.txt
+  # rocprofv3 --kernel-trace --stats of the other two single-GPU headline configurations (cfg 3; cfg 5's rank slab, both f64 decoders):
+  # cheap (kernel trace only), and in THIS call in case it is the only one the round gets -- the PMC passes of these are in `explain`
+  (echo "== cfg 3 (2D float64 8192x8192)"; timeout 200 bash tools/kernel_times.sh --config 3
+   echo "== cfg 5 slab (3D float64 128x1024x1024, decompress only), 128 work-items"; timeout 200 bash tools/kernel_times.sh --config 5 --f64-work-items 128
+   echo "== cfg 5 slab, 256 work-items"; timeout 200 bash tools/kernel_times.sh --config 5 --f64-work-items 256) > ${O}_kernel_times_f64.txt 2>&1
+  cat ${O}_kernel_times_f64.txt
   ;;
 explain)
   # variants present in ndzip_amd/_variants/ decide the A/B legs:
@@ -111,7 +117,7 @@ poll)
   ;;
 collect)
   dst=${3:-$tag}
-  for f in rocminfo smoke gputest variant_parity bench_n1.json configs workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d \
+  for f in rocminfo smoke gputest variant_parity bench_n1.json configs kernel_times_f64 workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d \
            rocprofv3_summary_f64_3d_decode_256 rocprofv3_summary_f64_3d_decode_128 ab_variants ab_variants_cfg1 ab_variants_f64_2d \
            ab_variants_f64_3d phase_timing two_process_stress; do
     for ext in "" .txt; do
