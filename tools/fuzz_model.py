@@ -4,7 +4,8 @@ against the oracle: streams bit for bit, decompress(compress(x)) == x.  Build th
 as b; b.build()") when running several seeds side by side.  Round 3: seeds 11-14 x 400, 21-24 x 300, 31-34 x 2500 -- 12 800 cases, all equal; and seeds 41-44 x 700 on the
 AddressSanitizer build of the model (LD_PRELOAD of the sanitizer runtime, WAVESIM_VARIANT=asan as in tests/test_wavesim_asan.py): clean.
 Second session of round 3 (dense f64 decoder path, bitop3 complement, backward f32 gather): seeds 51-54 x 600, all equal.
-Fourth session of round 3 (64-bit rotl1 / rotr1 as two v_alignbit_b32): seeds 61-64 x 300, all equal."""
+Fourth session of round 3 (64-bit rotl1 / rotr1 as two v_alignbit_b32): seeds 61-64 x 300, all equal.
+Round 5 (EXEC-masked f64 compaction + dense path, swizzled f32 3D store rows, post-B3 reordering): seeds 141-144 x 400, all equal."""
 import sys, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
