@@ -116,26 +116,33 @@ NDZIP_DEV uint32_t launch_epoch_load(const uint32_t *tickets) {
     return __hip_atomic_load(tickets + epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 NDZIP_DEV uint32_t launch_epoch(uint32_t loaded) { return static_cast<uint32_t>(wave_uniform(static_cast<int>(loaded))); }
+// (`tid`: work-item id in a one-dimensional workgroup of at least 64; every work-item of the workgroup calls this)
 NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid, uint32_t *err, uint32_t *out_len, desc_ref desc) {
-    if (tid != 0) return;
+    if (tid >= 64) return;  // wavefront 0 stays together: its 64 lanes share the wipe below, work-item 0 does everything else
     uint32_t *done = tickets + ticket_classes * ticket_stride_words;
-    wait_for_own_memory_operations();
-    if (atomicAdd(done, 1u) == gridDim.x - 1) {
+    uint32_t last = 0;
+    if (tid == 0) {
+        wait_for_own_memory_operations();
+        last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    if (__shfl(last, 0, 64) == 0) return;
+    if (tid == 0) {
         for (uint32_t c = 0; c < num_classes; ++c) tickets[c * ticket_stride_words] = 0;
         *done = 0;
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) store_stream_length(out_len, 0u);
-        // Every other workgroup has left: nobody reads the epoch or a descriptor of this launch any more.  The next launch on this
-        // scratch runs under epoch + 1; when the 30-bit field starts over, a descriptor an old launch left behind could carry the
-        // new epoch again, so the scratch is wiped first (once in 2^30 launches; by this one work-item, with the descriptors' own
-        // write-through stores).
-        uint32_t next = desc.epoch + 1;
-        if (next >= epoch_limit) {
-            const uint32_t count = tickets[epoch_word + 1];
-            for (uint32_t i = 0; i < count; ++i) desc_store(desc.p + i, 0);
-            next = 1;
-        }
-        __hip_atomic_store(tickets + epoch_word, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // Every other workgroup has left: nobody reads the epoch or a descriptor of this launch any more.  The next launch on this
+    // scratch runs under epoch + 1; when the 30-bit field starts over, a descriptor an old launch left behind could carry the
+    // new epoch again, so the scratch is wiped first (once in 2^30 launches; 64 descriptors per step, with the descriptors' own
+    // write-through stores -- up to ~10^6 of them: one work-item alone would hold the launch's end for milliseconds).  The next
+    // launch is a kernel boundary away: it sees the wipe and the epoch however the two are ordered here.
+    uint32_t next = desc.epoch + 1;
+    if (next >= epoch_limit) {
+        const uint32_t count = tickets[epoch_word + 1];
+        for (uint32_t i = static_cast<uint32_t>(tid); i < count; i += 64) desc_store(desc.p + i, 0);
+        next = 1;
+    }
+    if (tid == 0) __hip_atomic_store(tickets + epoch_word, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- decoupled look-back over tile lengths ---------------------------------------------------------------------
