@@ -32,6 +32,9 @@ def _sources():
 
 
 ASAN_FLAGS = ("-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g1")
+# undefined behaviour in the kernels' C++ (shift counts, signed overflow, misaligned or out-of-range accesses the host compiler may
+# treat differently from hipcc): every finding aborts.  (vptr / function need RTTI and do not apply to this code.)
+UBSAN_FLAGS = ("-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-fno-sanitize=vptr,function", "-shared-libsan", "-fno-omit-frame-pointer", "-g1")
 
 
 def asan_runtime() -> str:

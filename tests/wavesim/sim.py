@@ -18,10 +18,10 @@ _sim = {}
 def load(variant: str = "", defines=()):
     """WAVESIM_VARIANT=asan in the environment (with the AddressSanitizer runtime LD_PRELOADed, tests/test_wavesim_asan.py)
     makes the default library the sanitised one."""
-    if not variant and os.environ.get("WAVESIM_VARIANT") == "asan":
-        variant = "asan"
+    if not variant and os.environ.get("WAVESIM_VARIANT") in ("asan", "ubsan"):
+        variant = os.environ["WAVESIM_VARIANT"]  # (ubsan: tools/ubsan_rehearsal.sh, with the UBSan runtime LD_PRELOADed)
     if variant not in _sim:
-        flags = simbuild.ASAN_FLAGS if variant == "asan" else ()
+        flags = simbuild.ASAN_FLAGS if variant == "asan" else simbuild.UBSAN_FLAGS if variant == "ubsan" else ()
         kflags = simbuild.LDSPROF_FLAGS if variant == "ldsprof" else ()
         if variant == "ldsprof":
             defines = tuple(defines) + ("WAVESIM_LDSPROF",)
