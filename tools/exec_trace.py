@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--decompress", action="store_true", help="a decompress kernel instead (one workgroup start to end)")
     ap.add_argument("--f64-work-items", type=int, default=0)
     ap.add_argument("--dims", type=int, default=3, choices=[1, 2, 3])
+    ap.add_argument("--ends", action="store_true", help="the prologue (kernel start to the first iteration's B1) and the drain (behind the last B4) instead")
     a = ap.parse_args()
     from ndzip_amd import hip
     from ndzip_amd.synth import synth_numpy
@@ -70,6 +71,16 @@ def main():
         got = sim.compress(data, cus=2, blocks_per_cu=2)  # 4 workgroups, 16 tiles each
     assert np.array_equal(got, oracle.compress(data))
     bars = [i for i, l in enumerate(log) if "s_barrier" in l[2]]
+    if a.ends:
+        last_b4 = bars[-2] if len(bars) % 4 == 2 else bars[-1]  # (the drain has one barrier of its own)
+        for title, lo, hi in (("prologue", 0, bars[1]), ("drain", bars[-2], len(log) - 1)):
+            print(f"## {title}")
+            prev = log[lo][0] if lo else 0
+            for n, addr, text in log[lo:hi + 1]:
+                print(f"+{n - prev:5d}  {addr:#07x}  {text}")
+                prev = n
+        print(f"+{count[0] - prev:5d}  (end of the kernel)")
+        return
     start, end = bars[1 + 4 * 2], bars[1 + 4 * 3]  # the prologue's barrier and two iterations skipped; four barriers per iteration
     prev = log[start][0]
     for n, addr, text in log[start:end + 1]:
