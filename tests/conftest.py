@@ -70,7 +70,24 @@ def pytest_collection_modifyitems(config, items):
     # The driver runs `-m gpu -x`: the first failure ends the run.  Tests that could never be rehearsed on the functional model
     # (hardware_only: tools linked against the real runtime, the memory-mapped CLI path, multi-process runs) go to the END of the
     # session, so that a surprise in one of them cannot hide the parity results of everything that was rehearsed.
-    items.sort(key=lambda item: 1 if "hardware_only" in item.keywords else 0)  # (stable: the order inside each class stays)
+    # Inside the rehearsed part the same idea, by what has been on silicon before: the 32-bit profiles' parity tests first (their
+    # kernels descend from the ones round 1 ran on an MI355X), then everything that touches a 64-bit profile (three rounds of
+    # hand-written DPP sequences that never ran) and the tests that mix both, then the mechanisms that never ran at all (hipGraph
+    # capture, background load, the file tools) -- so that a failure in a later class still leaves the earlier classes' results.
+    mixed = ("test_known_answers_from_reference", "test_smoke_entry_point", "test_sharded_codec_single_rank", "test_full_size_configs")
+    late_files = ("test_hip_graph", "test_hip_stress", "test_hip_cli", "test_hip_sharded_mp", "test_hip_sharded_rccl", "test_cpp_adaptor")
+
+    def risk(item):
+        nid = item.nodeid.lower()
+        if "hardware_only" in item.keywords:
+            return 3
+        if any(f in nid for f in late_files):
+            return 2
+        if any(k in nid for k in ("float64", "f64", "double")) or any(m in nid for m in mixed):
+            return 1
+        return 0
+
+    items.sort(key=risk)  # (stable: the order inside each class stays)
     if not config.getoption("--rehearse-on-model"):
         return
     skip = pytest.mark.skip(reason="hardware only: not part of the rehearsal on the functional model")
