@@ -145,6 +145,15 @@ def test_f64_decoder_mappings_agree(hiplib, cuda_device, dims, work_items):
     dec.close()
 
 
+def test_zz_both_f64_decoder_kernels_agreed(hiplib, cuda_device):
+    """Every float64 test that did not choose a decoder mapping decoded with BOTH 64-bit kernels (tests/util.py::device_decompress) and
+    recorded disagreements instead of failing on the spot; this test -- sorted behind the 64-bit tests by tests/conftest.py -- is where
+    they surface.  (test_f64_decoder_mappings_agree checks each kernel against the ORACLE on its own.)"""
+    from tests import util
+
+    assert util.F64_DECODER_DISAGREEMENTS == [], util.F64_DECODER_DISAGREEMENTS[:10]
+
+
 @pytest.mark.parametrize("profile", PROFILES, ids=profile_id)
 @pytest.mark.parametrize("skew", [1, 3])
 def test_element_aligned_device_pointers(hiplib, cuda_device, profile, skew):

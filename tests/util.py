@@ -91,16 +91,26 @@ def device_decompress(stream: np.ndarray, dtype, extent, device=None, f64_work_i
     out = d_out[:n].cpu().numpy().view(dtype).reshape(extent)
     if np.dtype(dtype) == np.float64 and not f64_work_items:
         # the library decodes 64-bit profiles with one of two kernels (default_f64_work_items, codec_launch.hpp): every float64
-        # test that does not choose runs BOTH and requires the same bits, so neither kernel's coverage depends on the default
+        # test that does not choose runs BOTH, so neither kernel's coverage depends on the default.  A disagreement is RECORDED, not
+        # raised here: the calling test goes on with the default kernel's result, and test_hip_codec.py::
+        # test_zz_both_f64_decoder_kernels_agreed (sorted behind the 64-bit tests) fails with the list -- under `pytest -x` a defect
+        # of one decoder kernel then costs one test, not every float64 test of the suite.
         for work_items in (128, 256):
-            d_out.fill_(0x5A5A5A5A5A5A5A5A)
-            dec.set_f64_work_items(work_items)
-            dec.decompress(d_stream, d_out, extent)
-            dec.check()
-            other = d_out[:n].cpu().numpy().view(dtype).reshape(extent)
-            assert same_bits(other, out), f"the {work_items}-work-item 64-bit decoder differs from the default one"
+            try:
+                d_out.fill_(0x5A5A5A5A5A5A5A5A)
+                dec.set_f64_work_items(work_items)
+                dec.decompress(d_stream, d_out, extent)
+                dec.check()
+                other = d_out[:n].cpu().numpy().view(dtype).reshape(extent)
+                if not same_bits(other, out):
+                    F64_DECODER_DISAGREEMENTS.append(f"{work_items} work-items, extent {tuple(extent)}: bits differ from the default decoder's")
+            except Exception as e:
+                F64_DECODER_DISAGREEMENTS.append(f"{work_items} work-items, extent {tuple(extent)}: {type(e).__name__}: {e}")
     dec.close()
     return out
+
+
+F64_DECODER_DISAGREEMENTS = []  # (see device_decompress)
 
 
 def same_bits(a: np.ndarray, b: np.ndarray) -> bool:
