@@ -1,9 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the ndzip block encode/decode path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run, one rank per
-GPU over RCCL).  One "step" = one pass of the hot path over the synthetic grid, inputs already resident in HBM: compress,
-then decompress (`--compress-only` / `--decompress-only`: that half).  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`, one rank per GPU over RCCL.  With RANK / WORLD_SIZE in the
+environment (the driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) this process IS a
+rank; typed as is with N > 1 it starts the N ranks itself the same way and passes rank 0's line through (launch_ranks).
+One "step" = one pass of the hot path over the synthetic grid, inputs already resident in HBM: compress, then decompress
+(`--compress-only` / `--decompress-only`: that half).  Rank 0 prints ONE JSON line; its `ranks` object says how many ranks
+the process group saw, over which backend, and on which device each one ran.
 
 Workloads (`--config`, BASELINE.json `configs`):
   2 (default)  3D float32 512x512x512 per GPU -- the configuration the metric is quoted on.  At N GPUs the grid is
@@ -392,10 +395,50 @@ class Accelerator:
         return torch.cuda.Event(enable_timing=True)
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` typed as is (no RANK / WORLD_SIZE in the environment): start the N ranks ourselves, exactly the
+    way the driver would -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port
+    <free> bench.py <same arguments>` -- pass rank 0's JSON line through to our stdout (everything else the ranks or the launcher
+    print goes to stderr, so stdout carries the ONE line of the contract) and return the launcher's exit status.
+    NDZIP_BENCH_ENTRY names the script the ranks run instead of this file (tests/bench_on_model.py: the same main() with the
+    kernels on the functional model, which is how the CPU suite exercises this launch without a GPU)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    entry = os.environ.get("NDZIP_BENCH_ENTRY") or os.path.abspath(__file__)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only kind the host driver supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, physical_cores() // args.gpus)))
+    env["NDZIP_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), entry] + list(sys.argv[1:] if argv is None else argv)
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    lines = 0
+    for line in proc.stdout:
+        is_result = line.startswith('{"metric"')
+        lines += is_result
+        (sys.stdout if is_result else sys.stderr).write(line)
+        (sys.stdout if is_result else sys.stderr).flush()
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the ranks exited 0 but printed {lines} result lines", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.compress_only and args.decompress_only:
         raise SystemExit("--compress-only and --decompress-only exclude each other")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        rc = launch_ranks(args, argv)
+        if rc:
+            raise SystemExit(rc)
+        return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -415,10 +458,8 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with python -m torch.distributed.run --nproc-per-node N bench.py ...")
     # NDZIP_BENCH_SHARE_GPU=1 (self-test on a one-GPU box only): every rank uses cuda:0 and the group is gloo -- RCCL
     # refuses two ranks on one device; same code path otherwise
     share_gpu = world > 1 and os.environ.get("NDZIP_BENCH_SHARE_GPU") == "1"
@@ -531,8 +572,13 @@ def main(argv=None):
         t_decomp = float(mx[2]) if t_decomp is not None else None
         total_body_words = float(sm[3])
         ok = bool(mn[4] > 0.5)
+        ids = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([dev_index], dtype=torch.int64, device=device))
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "device_ids": [int(t[0]) for t in ids],
+                      "launched_by": "bench.py (torch.distributed.run child)" if os.environ.get("NDZIP_BENCH_SELF_LAUNCHED") else "torch.distributed.run"}
     else:
         total_body_words = float(body_len)
+        ranks_seen = {"world_size": 1, "backend": None, "device_ids": [dev_index], "launched_by": "python"}
 
     if rank == 0:
         wb = np_dtype.itemsize
@@ -584,6 +630,7 @@ def main(argv=None):
                 "parallelism": f"hypercube-range sharding x{world}" + ((" (RCCL all-gather of offsets + header" + (", behind the decompress launch)" if args.overlap_exchange else ")")) if world > 1 else ""),
             },
             "per_gpu": {},
+            "ranks": ranks_seen,
             "roofline": roofline,
             "roundtrip_bit_exact": ok,
         }

@@ -220,3 +220,33 @@ def test_main_with_two_ranks_over_gloo_on_the_model(tmp_path):
     d = json.loads([l for l in out0.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roundtrip_bit_exact"] is True and "cpu_baseline" not in d
     assert d["config"]["hypercubes"] == 2 * 8 and "64x32x32" in d["config"]["workload"] and "2 z-slab(s) of 32x32x32" in d["config"]["workload"]
+
+
+def test_gpus_2_typed_as_is_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with NO RANK / WORLD_SIZE in the environment (what the driver's single-command form and a
+    user at a shell type): bench.py starts the two ranks itself under torch.distributed.run, stdout carries exactly rank 0's
+    line, the exit status is the ranks'.  Here the ranks run tests/bench_on_model.py (kernels on the functional model, gloo)."""
+    import subprocess
+    import sys
+
+    from tests.wavesim import build as simbuild
+
+    simbuild.build()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NDZIP_BENCH_SHARE_GPU")}
+    env["NDZIP_BENCH_ENTRY"] = os.path.join(ROOT, "tests", "bench_on_model.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "32,32,32", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1, r.stdout
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["roundtrip_bit_exact"] is True and "cpu_baseline" not in d
+    assert d["ranks"] == {"world_size": 2, "backend": "gloo", "device_ids": [0, 0], "launched_by": "bench.py (torch.distributed.run child)"}
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr and "127.0.0.1" in r.stderr
+    # a failing rank is the launcher's failure too, and a silent rank 0 (exit 0, no line) is not a success either
+    for body, what in (("import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)", "rank 1 fails"), ("pass", "nobody prints")):
+        entry = tmp_path / "entry.py"
+        entry.write_text(body + "\n")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "32,32,32"],
+                           capture_output=True, text=True, env=dict(env, NDZIP_BENCH_ENTRY=str(entry)), cwd=str(tmp_path), timeout=600)
+        assert r.returncode != 0 and not r.stdout.strip(), what
