@@ -76,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--workgroups-per-cu", type=int, default=0, help="cap the persistent compress grid (0 = default: 4 per CU); 3 = the round-2 grid, for an A/B of the occupancy")
     ap.add_argument("--f64-work-items", type=int, default=0, choices=[0, 128, 256], help="64-bit decoder mapping: 0 = the library's default (128 work-items per hypercube, decompress_kernel, until the other is measured), 256 = decompress_kernel_wide; for an A/B of the two")
     ap.add_argument("--overlap-exchange", action="store_true", help="N > 1: leave the offset / header exchange in flight behind the decompress launch (opt-in until it has run over RCCL on a multi-GPU node; default: compress -> exchange -> decompress, every collective waited for)")
+    ap.add_argument("--native-exchange", action="store_true", help="drive the step through the C++ host of the sharded path (libndzip_hip_rccl.so, include/ndzip_hip_sharded.h: plan, buffers and "
+                    "the two all-gathers in C++ over its own ncclComm_t) instead of ndzip_amd.sharded.ShardedCodec (torch.distributed); same kernels, same stream -- opt-in until it has run on a multi-GPU node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true")
@@ -494,7 +496,14 @@ def main(argv=None):
     # for.  --overlap-exchange lets it run BEHIND the decompress launch instead, which decodes the rank's slab from its local
     # offsets and needs nothing from the other ranks (ndzip_amd/sharded.py: overlap_exchange) -- rehearsed over gloo on the
     # functional model and in tests/test_hip_sharded_rccl.py, opt-in until that test has passed on a multi-GPU node.
-    codec = ShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and args.overlap_exchange)
+    if args.native_exchange:
+        if args.overlap_exchange or args.workgroups_per_cu or args.f64_work_items:
+            raise SystemExit("--native-exchange has no --overlap-exchange / --workgroups-per-cu / --f64-work-items (A/B handles of the Python driver)")
+        from ndzip_amd import sharded_native
+
+        codec = sharded_native.NativeShardedCodec(np_dtype, global_extent, rank, world, device)
+    else:
+        codec = ShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and args.overlap_exchange)
     if args.workgroups_per_cu:
         codec.compressor.set_max_workgroups_per_cu(args.workgroups_per_cu)
     if args.f64_work_items:
@@ -554,7 +563,7 @@ def main(argv=None):
     t_decomp = None if mode == "compress" else sum(e[2].elapsed_time(e[3]) for e in events) / args.steps * 1e-3
 
     # ---- verification (outside the timed region): round trip is bit-exact ------------------------------------------
-    body_len = int(codec.body_len.cpu()[0]) & 0xFFFFFFFF
+    body_len = codec.body_words() if args.native_exchange else int(codec.body_len.cpu()[0]) & 0xFFFFFFFF
     ok = True
     if not args.no_verify and mode != "compress":
         it = torch.int32 if np_dtype == np.float32 else torch.int64
@@ -628,6 +637,7 @@ def main(argv=None):
                 "step": {"both": "compress then decompress", "compress": "compress only", "decompress": "decompress only"}[mode]
                         + ", inputs resident in HBM",
                 "parallelism": f"hypercube-range sharding x{world}" + ((" (RCCL all-gather of offsets + header" + (", behind the decompress launch)" if args.overlap_exchange else ")")) if world > 1 else ""),
+                "host": "C++ (libndzip_hip_rccl.so: ndzip_hip_sharded_*, RCCL called from C++)" if args.native_exchange else "Python (ndzip_amd.sharded.ShardedCodec over torch.distributed)",
             },
             "per_gpu": {},
             "ranks": ranks_seen,

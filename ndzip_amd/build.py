@@ -67,6 +67,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or jobs or _stale(STAGES_OUT, stage_objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", STAGES_OUT, *stage_objs])
     build_cli(force=force, verbose=verbose)
+    build_rccl(force=force, verbose=verbose)
     return OUT
 
 
@@ -134,6 +135,28 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
             if r.returncode != 0:
                 raise RuntimeError(f"g++ failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
     return CLI_OUT
+
+
+RCCL_OUT = os.path.join(HERE, "libndzip_hip_rccl.so")
+RCCL_SOURCES = ["sharded.cc", "sharded_rccl.cc"]
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def build_rccl(force: bool = False, verbose: bool = False) -> str:
+    """ndzip_amd/libndzip_hip_rccl.so (include/ndzip_hip_sharded.h): the C++ host of the multi-GPU path -- plain host code over the C
+    ABI of libndzip_hip.so, the HIP runtime's memory calls and RCCL.  No device code: kernels_fingerprint() does not cover it."""
+    srcs = [os.path.join(CSRC, f) for f in RCCL_SOURCES]
+    deps = srcs + [OUT, os.path.join(HERE, "..", "include", "ndzip_hip.h"), os.path.join(HERE, "..", "include", "ndzip_hip_sharded.h"), os.path.abspath(__file__)]
+    if force or _stale(RCCL_OUT, deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra", "-DNDZIP_HIP_BUILD", "-D__HIP_PLATFORM_AMD__",
+               "-I" + os.path.join(ROCM, "include"), "-o", RCCL_OUT, *srcs, "-L" + HERE, "-lndzip_hip", "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lamdhip64",
+               "-Wl,-rpath,$ORIGIN", "-Wl,--no-undefined"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return RCCL_OUT
 
 
 TEST_VARIANT_SPIN0 = os.path.join(HERE, "_variants", "spin0.so")

@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--case", action="append", required=True)
     ap.add_argument("--async-header-gather", action="store_true")
     ap.add_argument("--overlap-exchange", action="store_true", help="decode from local offsets while the exchange runs behind it")
+    ap.add_argument("--native", action="store_true", help="the C++ host (libndzip_hip_rccl.so, include/ndzip_hip_sharded.h: its own ncclComm_t, "
+                                                          "RCCL called from C++) instead of the torch.distributed driver")
     args = ap.parse_args()
     rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -68,6 +70,10 @@ def main():
         for i, case in enumerate(args.case):
             dtype, extent, full = case_data(case)
             wdt = np.uint32 if np.dtype(dtype).itemsize == 4 else np.uint64
+            if args.native:
+                native_case(args, i, dtype, extent, full, wdt, rank, world, device)
+                dist.barrier()
+                continue
             codec = ShardedCodec(dtype, extent, rank, world, device, async_header_gather=args.async_header_gather,
                                  overlap_exchange=args.overlap_exchange)
             sh = codec.shard
@@ -87,6 +93,43 @@ def main():
                      roundtrip=bool(np.array_equal(out.cpu().numpy().reshape(-1).view(wdt), slab.cpu().numpy().reshape(-1).view(wdt))))
             dist.barrier()
     dist.destroy_process_group()
+
+
+def native_case(args, i, dtype, extent, full, wdt, rank, world, device):
+    """The same case through ndzip_amd.sharded_native.NativeShardedCodec.  What the test process reads is taken from the rank's
+    pieces of the single stream (ndzip_hip_sharded_write_stream into a host buffer of the whole stream's size) and its layout."""
+    import ctypes as C
+
+    import torch
+
+    from ndzip_amd import sharded_native
+
+    kw = {}
+    if args.model:  # sharded.cc compiled against the functional model; gloo carries the one-function exchange
+        from tests.test_sharded_native_cpu import _gloo_table
+        from tests.wavesim import build as simbuild
+
+        sharded_native._lib = sharded_native._bind(C.CDLL(simbuild.build_sharded()), rccl=False)
+        table, _ = _gloo_table(world)
+        kw["collectives"] = table
+    codec = sharded_native.NativeShardedCodec(dtype, extent, rank, world, device, **kw)
+    sh = codec.shard
+    slab = torch.from_numpy(np.ascontiguousarray(full[sh.start0: sh.start0 + sh.extent[0]])).to(device)
+    out = torch.zeros_like(slab)
+    for _ in range(3):
+        codec.compress(slab)
+        codec.decompress(out)
+    codec.check()
+    lay = codec.stream_layout()
+    stream = np.zeros(int(lay.stream_words), dtype=wdt)
+    codec.write_stream(stream, with_header=True)
+    nhc = sum(s.num_hypercubes for s in codec.shards)
+    r0, r1, b0, b1 = int(lay.runs_offset_words), int(lay.runs_offset_words + lay.runs_words), int(lay.border_offset_words), int(lay.border_offset_words + lay.border_words)
+    np.savez(os.path.join(args.out, f"rank{rank}_case{i}.npz"),
+             header=stream.view(np.uint32)[:nhc].copy(), body=np.concatenate([stream[r0:r1], stream[b0:b1]]),
+             base=r0 - int(lay.header_words),
+             roundtrip=bool(np.array_equal(out.cpu().numpy().reshape(-1).view(wdt), slab.cpu().numpy().reshape(-1).view(wdt))))
+    codec.close()
 
 
 if __name__ == "__main__":

@@ -162,6 +162,33 @@ def test_main_produces_the_contract_line_on_the_model(monkeypatch, capsys, argv,
         assert cb["kind"] == "reference" and "cpu_reference_serial_cfg1" in d and d["cpu_reference_serial_cfg1"]["cores"] == 1
 
 
+def test_native_exchange_single_rank_on_the_model(monkeypatch, capsys):
+    """bench.py --native-exchange at N = 1: the step goes through libndzip_hip_rccl's driver (here: sharded.cc on the model), the line
+    is the same contract line and says which host produced it."""
+    import ctypes
+
+    from ndzip_amd import sharded_native
+    from tests.test_sharded_native_cpu import _gloo_table
+    from tests.wavesim import build as simbuild
+    from tests.wavesim import sim
+
+    monkeypatch.setattr(bench, "Accelerator", _HostAccelerator)
+    monkeypatch.setattr(sharded_native, "_lib", sharded_native._bind(ctypes.CDLL(simbuild.build_sharded()), rccl=False))
+    real = sharded_native.NativeShardedCodec
+    monkeypatch.setattr(sharded_native, "NativeShardedCodec", lambda *a, **k: real(*a, collectives=_gloo_table(1)[0], **k))
+    with sim.active():
+        bench.main(["--shape", "130,200", "--dtype", "float64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--native-exchange"])
+        with pytest.raises(SystemExit, match="--native-exchange has no"):
+            bench.main(["--shape", "32,32,32", "--native-exchange", "--workgroups-per-cu", "2"])
+    d = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert d["roundtrip_bit_exact"] is True and d["n_gpus"] == 1 and d["config"]["host"].startswith("C++ (libndzip_hip_rccl.so")
+    # the same workload through the Python driver: same stream length, hence the same ratio
+    with sim.active():
+        bench.main(["--shape", "130,200", "--dtype", "float64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    d2 = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert d2["config"]["compression_ratio"] == d["config"]["compression_ratio"] and d2["config"]["host"].startswith("Python")
+
+
 def test_traffic_is_reported_only_for_counters_taken_on_these_kernels(monkeypatch, capsys, tmp_path):
     """profiles/traffic.json entries carry the fingerprint of the device-code sources they were measured on; an entry of other
     kernels (the committed round-1 one, say) leaves roofline.traffic null and says why."""
@@ -222,7 +249,8 @@ def test_main_with_two_ranks_over_gloo_on_the_model(tmp_path):
     assert d["config"]["hypercubes"] == 2 * 8 and "64x32x32" in d["config"]["workload"] and "2 z-slab(s) of 32x32x32" in d["config"]["workload"]
 
 
-def test_gpus_2_typed_as_is_starts_its_own_ranks(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--native-exchange"]], ids=["python-driver", "cpp-host"])
+def test_gpus_2_typed_as_is_starts_its_own_ranks(tmp_path, extra):
     """`python bench.py --gpus 2 ...` with NO RANK / WORLD_SIZE in the environment (what the driver's single-command form and a
     user at a shell type): bench.py starts the two ranks itself under torch.distributed.run, stdout carries exactly rank 0's
     line, the exit status is the ranks'.  Here the ranks run tests/bench_on_model.py (kernels on the functional model, gloo)."""
@@ -234,7 +262,8 @@ def test_gpus_2_typed_as_is_starts_its_own_ranks(tmp_path):
     simbuild.build()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NDZIP_BENCH_SHARE_GPU")}
     env["NDZIP_BENCH_ENTRY"] = os.path.join(ROOT, "tests", "bench_on_model.py")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "32,32,32", "--steps", "2", "--warmup", "1"],
+    simbuild.build_sharded()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "32,32,32", "--steps", "2", "--warmup", "1", *extra],
                        capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = [l for l in r.stdout.splitlines() if l.strip()]
@@ -243,6 +272,9 @@ def test_gpus_2_typed_as_is_starts_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["roundtrip_bit_exact"] is True and "cpu_baseline" not in d
     assert d["ranks"] == {"world_size": 2, "backend": "gloo", "device_ids": [0, 0], "launched_by": "bench.py (torch.distributed.run child)"}
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr and "127.0.0.1" in r.stderr
+    assert d["config"]["host"].startswith("C++ (libndzip_hip_rccl.so" if extra else "Python (ndzip_amd.sharded.ShardedCodec")
+    if extra:
+        return
     # a failing rank is the launcher's failure too, and a silent rank 0 (exit 0, no line) is not a success either
     for body, what in (("import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)", "rank 1 fails"), ("pass", "nobody prints")):
         entry = tmp_path / "entry.py"

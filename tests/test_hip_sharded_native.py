@@ -1,0 +1,137 @@
+"""The C++ host of the multi-GPU path (include/ndzip_hip_sharded.h -> ndzip_amd/libndzip_hip_rccl.so) on hardware: the example
+program tests/cpp/sharded_host.cc -- one process per GPU, its own ncclComm_t, RCCL called from C++ -- must write the oracle's
+single stream for the whole array and decode every slab back from it; NativeShardedCodec (the ctypes binding) on one GPU must do
+the same from Python.  With one visible GPU the plan has one shard (no communicator); with N >= 2 the program runs N ranks over
+RCCL (the N-rank Python-driven run of the same library is tests/test_hip_sharded_rccl.py, mode native-cpp-host).
+The CPU suite compiles and links the program (here) and runs the library's transport-independent half on the kernels' functional
+model over gloo (tests/test_sharded_native_cpu.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ndzip_amd.synth import synth_numpy
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "sharded_host.cc")
+LIBDIR = os.path.join(ROOT, "ndzip_amd")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def build_host(exe):
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
+                        "-I" + os.path.join(ROOT, "include"), SRC, "-o", str(exe), "-L" + LIBDIR, "-lndzip_hip_rccl", "-lndzip_hip",
+                        "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath," + os.path.join(ROCM, "lib")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return str(exe)
+
+
+def test_example_host_compiles_and_links_against_the_sharded_library(tmp_path):
+    exe = build_host(tmp_path / "sharded_host")
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+    assert "libndzip_hip_rccl.so" in needed  # (which in turn needs libndzip_hip.so: the kernels)
+    # (rccl.h is not needed by a host that uses the bootstrap helpers: the program includes only the C ABI and the HIP runtime API)
+    with open(SRC) as f:
+        assert "rccl.h" not in f.read()
+
+
+def _gpus():
+    try:
+        import torch
+
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+def run_host(tmp_path, exe, dtype, extent, world):
+    data = synth_numpy(extent, dtype, seed=61, noise_mask=0xFF)
+    (tmp_path / "in.bin").write_bytes(data.tobytes())
+    out = tmp_path / "stream.bin"
+    if out.exists():
+        out.unlink()
+    idf = tmp_path / "nccl_id"
+    if idf.exists():
+        idf.unlink()
+    base = [exe, "--world", str(world), "--id-file", str(idf), "--dtype", "f32" if np.dtype(dtype).itemsize == 4 else "f64",
+            "--extent", ",".join(map(str, extent)), "--in", str(tmp_path / "in.bin"), "--out", str(out)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen(base + ["--rank", str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, start_new_session=True)
+             for r in range(world)]
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=300)
+            logs.append(o)
+    except subprocess.TimeoutExpired:
+        import signal
+
+        for p in procs:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        pytest.fail(f"{world} ranks of sharded_host did not finish\n" + "\n".join(logs)[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    want = oracle.compress(data)
+    got = np.fromfile(out, dtype=want.dtype)
+    assert len(got) == len(want) and np.array_equal(got, want), "the ranks' pieces do not add up to the reference stream"
+    assert all(": ok" in l for l in logs)
+
+
+@pytest.mark.gpu
+@pytest.mark.hardware_only
+@pytest.mark.parametrize("dtype,extent", [(np.float32, (70, 50, 36)), (np.float64, (130, 200)), (np.float32, (3 * 4096 + 17,)), (np.float64, (40, 33, 18)),
+                                          (np.float32, (10, 70))])
+def test_example_host_single_gpu(tmp_path, dtype, extent):
+    run_host(tmp_path, build_host(tmp_path / "sharded_host"), dtype, extent, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.hardware_only
+@pytest.mark.skipif(_gpus() < 2, reason="needs at least 2 GPUs (one process per GPU, RCCL called from C++)")
+@pytest.mark.parametrize("dtype,extent_of", [(np.float32, lambda w: (16 * w, 32, 48)), (np.float32, lambda w: (16 * (w + 1) + 5, 37, 41)),
+                                             (np.float64, lambda w: (64 * (w + 1), 200)), (np.float64, lambda w: (4096 * (2 * w + 1) + 77,))],
+                         ids=["f32-3d-equal", "f32-3d-unequal-border", "f64-2d", "f64-1d"])
+def test_example_host_all_gpus_over_rccl(tmp_path, dtype, extent_of):
+    world = _gpus()
+    run_host(tmp_path, build_host(tmp_path / "sharded_host"), dtype, extent_of(world), world)
+
+
+@pytest.mark.gpu
+@pytest.mark.hardware_only
+@pytest.mark.parametrize("dtype,extent", [(np.float32, (70, 50, 36)), (np.float64, (130, 200)), (np.float64, (4096 * 3 + 5,))])
+def test_native_codec_from_python_single_gpu(dtype, extent):
+    """NativeShardedCodec with one shard on cuda:0: stream == oracle, decode of the resident stream and of a loaded one."""
+    import torch
+
+    from ndzip_amd.sharded_native import NativeShardedCodec
+
+    wdt = np.uint32 if np.dtype(dtype).itemsize == 4 else np.uint64
+    data = synth_numpy(extent, dtype, seed=62, noise_mask=0xFF)
+    want = oracle.compress(data)
+    dev = torch.device("cuda", 0)
+    codec = NativeShardedCodec(dtype, extent, 0, 1, dev)
+    slab = torch.from_numpy(data).to(dev)
+    out = torch.zeros_like(slab)
+    for _ in range(2):
+        codec.compress(slab)
+        codec.decompress(out)
+    codec.check()
+    lay = codec.stream_layout()
+    assert lay.stream_words == len(want)
+    got = np.zeros(len(want), dtype=wdt)
+    codec.write_stream(got, with_header=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(out.cpu().numpy().view(wdt), data.view(wdt))
+    back = NativeShardedCodec(dtype, extent, 0, 1, dev)
+    back.load(want)
+    out.zero_()
+    back.decompress(out)
+    back.check()
+    assert np.array_equal(out.cpu().numpy().view(wdt), data.view(wdt))
+    codec.close()
+    back.close()

@@ -104,5 +104,32 @@ def _build_locked(OUT, BUILD, FLAGS, verbose, extra_flags, kernel_flags) -> str:
     return OUT
 
 
+def build_sharded(force: bool = False, verbose: bool = False) -> str:
+    """tests/wavesim/libndzip_hip_sharded_wavesim.so: the product's multi-GPU host (ndzip_amd/csrc/sharded.cc, unchanged; the RCCL file
+    is left out -- the CPU tests supply the collectives table) compiled against the model's runtime header and linked against the model
+    library, so that include/ndzip_hip_sharded.h can be driven where there is no GPU."""
+    model = build()
+    out = os.path.join(HERE, "libndzip_hip_sharded_wavesim.so")
+    src = os.path.join(CSRC, "sharded.cc")
+    deps = [src, model, os.path.join(ROOT, "include", "ndzip_hip.h"), os.path.join(ROOT, "include", "ndzip_hip_sharded.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
+            os.path.abspath(__file__)]
+    if not force and os.path.exists(out) and all(os.path.getmtime(f) <= os.path.getmtime(out) for f in deps):
+        return out
+    with open(os.path.join(HERE, "_build", ".lock_sharded"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(out) and all(os.path.getmtime(f) <= os.path.getmtime(out) for f in deps):
+            return out
+        tmp = out + f".tmp{os.getpid()}"
+        cmd = [CXX, *FLAGS, "-DNDZIP_HIP_BUILD", "-shared", "-I", HERE, "-o", tmp, src, "-L" + HERE, "-l:" + os.path.basename(model), "-Wl,-rpath,$ORIGIN",
+               "-Wl,--no-undefined"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"wavesim sharded build failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
