@@ -52,6 +52,13 @@ typedef struct ndzip_hip_decompressor ndzip_hip_decompressor;
 /* Human-readable description of the last error on the calling thread ("" if none). */
 NDZIP_HIP_API const char *ndzip_hip_last_error(void);
 
+/* Version of THIS interface the library was built from.  It changes whenever the signature or the meaning of an existing entry
+ * point does (2: ndzip_hip_compressor_offset_header_gathered took `world`), not when entry points are added: a binding generated
+ * from one header and loaded against a library of another must compare it with NDZIP_HIP_ABI_VERSION before the first call
+ * (ndzip_amd/hip.py does; a C or C++ program that links the library gets the check from the linker and the header together). */
+#define NDZIP_HIP_ABI_VERSION 2
+NDZIP_HIP_API int ndzip_hip_abi_version(void);
+
 /* Library / device identification: writes the gfx arch name of the current device (e.g. "gfx950") and its CU
  * count.  Fails with NDZIP_HIP_ERR_NO_DEVICE when no GPU is visible. */
 NDZIP_HIP_API int ndzip_hip_device_info(char *arch, size_t arch_capacity, int *num_compute_units);
@@ -113,7 +120,9 @@ NDZIP_HIP_API int ndzip_hip_compressor_offset_header_device(
  * launch between the two collectives of the multi-GPU path, no host synchronisation.
  * Stream offsets are index_type = uint32 (include/ndzip/ndzip.hh:20): the sums are taken in 64 bits over ALL `world` shards, and
  * when the hypercube runs of the whole plan exceed 2^32 - 1 words the handle's error word gets the bit that
- * ndzip_hip_compressor_check reports as "sharded stream exceeds the format's 32-bit offsets" -- on every rank alike. */
+ * ndzip_hip_compressor_check reports as "sharded stream exceeds the format's 32-bit offsets" -- on every rank alike -- and the
+ * entries are left LOCAL with *d_base_out = 0 (the rank can still decode its own slab; nothing wrapped is ever published).
+ * ndzip_hip_compressor_check is therefore MANDATORY before the globalised header is consumed. */
 NDZIP_HIP_API int ndzip_hip_compressor_offset_header_gathered(ndzip_hip_compressor *c, uint32_t *d_header, uint32_t count,
         const uint32_t *d_lengths, const uint32_t *d_borders, uint32_t rank, uint32_t world, uint32_t *d_base_out);
 

@@ -108,11 +108,16 @@ __global__ void offset_header_gathered_kernel(uint32_t *header, uint32_t count, 
         if (r == rank) base = total;
         total += static_cast<uint64_t>(lengths[r]) - borders[r];
     }
-    const uint32_t base32 = static_cast<uint32_t>(base);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += base32;
+    // A plan whose runs do not fit the format's 32-bit offsets has no global header: the entries stay LOCAL and the base 0 -- a
+    // state the rank can still decode its own slab from -- instead of entries wrapped modulo 2^32, and the error word says why.
+    const bool overflow = total > 0xffffffffull;
+    const uint32_t base32 = overflow ? 0u : static_cast<uint32_t>(base);
+    if (base32 != 0) {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) header[i] += base32;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (base_out) *base_out = base32;
-        if (total > 0xffffffffull) atomicOr(err, err_offset_overflow_bit);
+        if (overflow) atomicOr(err, err_offset_overflow_bit);
     }
 }
 
@@ -182,6 +187,8 @@ struct ndzip_hip_decompressor {
 extern "C" {
 
 const char *ndzip_hip_last_error(void) { return g_last_error.c_str(); }
+
+int ndzip_hip_abi_version(void) { return NDZIP_HIP_ABI_VERSION; }
 
 int ndzip_hip_device_info(char *arch, size_t arch_capacity, int *num_compute_units) {
     int cus = 0;

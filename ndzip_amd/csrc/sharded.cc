@@ -181,6 +181,9 @@ int create(int dtype, int dims, const uint32_t *global_extent, uint32_t rank, ui
     if (!out) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
     *out = nullptr;
     if (!coll || !coll->all_gather_u32) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "no all_gather_u32 in the collectives table");
+    if (ndzip_hip_abi_version() != NDZIP_HIP_ABI_VERSION) {
+        return fail(NDZIP_HIP_ERR_RUNTIME, "libndzip_hip.so has ABI version %d, libndzip_hip_rccl.so was built against %d", ndzip_hip_abi_version(), NDZIP_HIP_ABI_VERSION);
+    }
     ndzip_hip_shard mine{};
     if (int st = plan(dtype, dims, global_extent, rank, world, &mine)) return st;
     auto *s = new (std::nothrow) ndzip_hip_sharded;

@@ -43,8 +43,10 @@ _lib = None
 _stages_lib = None
 
 # every symbol include/ndzip_hip.h declares (the CPU test suite checks the library exports all of them)
+ABI_VERSION = 2  # NDZIP_HIP_ABI_VERSION of the include/ndzip_hip.h this binding was written against
 EXPORTED_SYMBOLS = (
     "ndzip_hip_last_error",
+    "ndzip_hip_abi_version",
     "ndzip_hip_device_info",
     "ndzip_hip_compressed_length_bound",
     "ndzip_hip_num_hypercubes",
@@ -159,6 +161,15 @@ def _bind(L, strict: bool = True):
     if not strict:
         L = _Tolerant(L)
     L.ndzip_hip_last_error.restype = C.c_char_p
+    if strict:
+        # (a library built from another revision of the header: an argument list may have changed under the same symbol name)
+        try:
+            L.ndzip_hip_abi_version.argtypes, L.ndzip_hip_abi_version.restype = [], C.c_int
+            have = L.ndzip_hip_abi_version()
+        except AttributeError:
+            have = 1
+        if have != ABI_VERSION:
+            raise ImportError(f"libndzip_hip: ABI version {have}, this binding is written against {ABI_VERSION} (rebuild: python -m ndzip_amd.build)")
     L.ndzip_hip_device_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
     L.ndzip_hip_compressed_length_bound.argtypes = [C.c_int, C.c_int, _U32P, C.POINTER(C.c_uint64)]
     L.ndzip_hip_num_hypercubes.argtypes = [C.c_int, _U32P, _U32P]

@@ -112,20 +112,31 @@ def base_from_lengths(lengths, borders, rank: int) -> int:
 
 
 def check_global_extent(dtype, extent: Sequence[int]) -> None:
-    """What the stream format can carry at all (uint32 element count; uint32 offsets even if nothing compresses): ValueError otherwise.
-    Eight legal slabs (each < 2^32 elements) can form a global array that is not."""
+    """What the stream format can carry at all: ValueError otherwise, naming the limit.  Eight legal slabs (each < 2^32 elements)
+    can form a global array that is not.  Three separate uint32 quantities (include/ndzip/ndzip.hh:20): the element count; the
+    header's offsets, which address hypercube runs only (src/ndzip/common.hh:351-358) -- held against the runs' bound, not the
+    whole stream's; and the stream length word -- held against compressed_length_bound.  Host arithmetic only (the same three
+    rules as libndzip_hip_rccl's check_global_extent, ndzip_amd/csrc/sharded.cc)."""
     import numpy as np
 
-    import ndzip_amd
-
+    extent = tuple(int(x) for x in extent)
     n = 1
     for x in extent:
-        n *= int(x)
+        n *= x
     if n > INDEX_MAX:
-        raise ValueError(f"extent {tuple(extent)} has {n} elements: more than index_type (uint32) counts")
-    bound_words = ndzip_amd.compressed_length_bound(dtype, tuple(int(x) for x in extent))  # (in words of the profile)
-    if bound_words > INDEX_MAX:
-        raise ValueError(f"extent {tuple(extent)}: compressed_length_bound = {bound_words} words does not fit the format's 32-bit offsets")
+        raise ValueError(f"extent {extent} has {n} elements: more than index_type (uint32) counts")
+    bits = np.dtype(dtype).itemsize * 8
+    side = SIDE[len(extent)]
+    nhc = 1
+    for x in extent:
+        nhc *= x // side
+    runs = nhc * (4096 + 4096 // bits)  # an incompressible hypercube: 4096 words + 4096 / B head words (common.cc:31-55)
+    if runs > INDEX_MAX:
+        raise ValueError(f"extent {extent}: {nhc} hypercubes can take {runs} words, more than the format's 32-bit offsets address")
+    header = nhc if np.dtype(dtype).itemsize == 4 else (nhc + 1) // 2
+    bound = header + runs + (n - nhc * 4096)
+    if bound > INDEX_MAX:
+        raise ValueError(f"extent {extent}: compressed_length_bound = {bound} words does not fit the uint32 stream length")
 
 
 class ShardedCodec:

@@ -241,11 +241,22 @@ def _overflow_rank_main(rank, world, port, out_dir):
             codec.check()
         except hip.NdzipHipError as e:
             message = str(e)
+        # nothing wrapped is ever published: on overflow the entries stay LOCAL and the base 0, a state the rank still decodes its
+        # own slab from (the error word says the global stream does not exist)
+        codec.compress_local(local)
+        local_entries = codec.header_local.numpy().view(np.uint32)[: sh.num_hypercubes].copy()
+        codec.globalise()  # (lens_all still holds the forged lengths)
+        out = torch.zeros_like(local)
+        codec.decompress(out)
+        kept_local = bool(np.array_equal(codec.header_local.numpy().view(np.uint32)[: sh.num_hypercubes], local_entries)) and \
+            int(codec.base32.numpy().view(np.uint32)[0]) == 0 and bool(np.array_equal(out.numpy().view(np.uint32), local.numpy().view(np.uint32)))
+        with pytest.raises(hip.NdzipHipError, match="32-bit offsets"):
+            codec.check()
         codec.compress(local)  # the error word was cleared by check(): the handle works again
         codec.check()
         again = int(codec.base32.numpy().view(np.uint32)[0])
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
-        f.write(f"{base_ok}\n{again}\n{message}\n")
+        f.write(f"{base_ok}\n{again}\n{message}\n{kept_local}\n")
     dist.destroy_process_group()
 
 
@@ -261,6 +272,6 @@ def test_overflowing_offsets_raise_on_every_rank_on_the_model_over_gloo(tmp_path
     world, port = 3, _free_port()
     mp.spawn(_overflow_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
-        base_ok, again, message = (tmp_path / f"rank{r}.txt").read_text().split("\n")[:3]
-        assert base_ok == again and (r > 0) == (int(base_ok) > 0)
+        base_ok, again, message, kept_local = (tmp_path / f"rank{r}.txt").read_text().split("\n")[:4]
+        assert base_ok == again and (r > 0) == (int(base_ok) > 0) and kept_local == "True"
         assert "32-bit offsets" in message and "0x4" in message, (r, message)
