@@ -65,7 +65,7 @@ def test_no_memory_drain_between_the_copy_out_and_the_transposes():
     """The order hipcc gives the tail of a compress iteration, from the EXECUTED stream of the built kernel (tools/exec_trace.py):
     behind B3 the copy-out's stores are issued and the ~260 instructions of the transposes follow WITHOUT a wait for all outstanding
     memory operations in between; the ticket atomic is not issued in that stretch (it was drawn behind B2).  Round 5 found both
-    wrong in the binary although the source suggested otherwise: this pins the property against the next
+    wrong in the binary although the source suggested otherwise (docs/rounds.md section 5): this pins the property against the next
     compiler release or an innocent-looking edit."""
     for args, min_stores in (((), 3), (("--f64",), 3), (("--f64", "--dims", "2"), 3), (("--dims", "1"), 3)):  # cfg 2, 3D f64, cfg 3, cfg 1
         ops = _trace(*args)

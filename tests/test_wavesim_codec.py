@@ -337,7 +337,7 @@ def test_f32_3d_with_an_odd_hypercube_count_along_x_takes_the_unpaired_loads(sha
 @pytest.mark.parametrize("resident", [16, 20])
 def test_sixteen_ticket_classes_with_a_partly_resident_grid(resident, monkeypatch):
     """The same with 16 ticket classes (grids of 16+ workgroups): what the scheme needs is one live drawer per class, i.e. the
-    first 16 workgroups resident ("Tile order = ticket order"); workgroups 16.. of the 24 may start late or never."""
+    first 16 workgroups resident (docs/rounds.md section 4, "Tile order = ticket order"); workgroups 16.. of the 24 may start late or never."""
     monkeypatch.setenv("WAVESIM_MAX_RESIDENT", str(resident))
     for dtype, shape in ((np.float32, (6 * 16, 4 * 16, 4 * 16)), (np.float64, (7 * 64, 6 * 64 + 5))):
         data = synth_numpy(shape, dtype, seed=10)

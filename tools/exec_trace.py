@@ -2,7 +2,7 @@
 """EXECUTED order of barriers, vector-memory operations and s_waitcnt vmcnt of ONE wavefront of a compress kernel, one iteration of
 its persistent loop (CPU; test tooling: the built gfx950 code object on tests/gfx950_exec.py with a trace hook).  A listing's block
 order is not execution order, and where hipcc places a wait -- or sinks a stretch of register-only work -- decides what a wavefront
-overlaps with what; round 5 found a full memory drain in front of ~270 independent instructions this way.
+overlaps with what; round 5 found a full memory drain in front of ~270 independent instructions this way (docs/rounds.md section 5).
 Each line: +instructions executed since the previous line, address, instruction.
 usage: exec_trace.py [--wave 0] [--f64] [--dims 3] [--decompress] [--lib ndzip_amd/_variants/<name>.so] [--lgkm]"""
 import argparse

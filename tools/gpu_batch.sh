@@ -62,7 +62,7 @@ explain)
   #   trearly = the transposes pinned in front of the look-back and B3 (round 1's measured order) instead of overlapping the copy-out's stores;
   #   cobatch2 = copy-out with the LDS reads of two vectors per work-item in flight before the first store (five serial LDS round trips per
   #   wavefront become three; four at a time spill at 128 VGPRs -- what round 1's "unrolled x3: 0.249 vs 0.240" was);
-  #   winpub = look-back window read a third of an iteration later, still ahead of the late prefetch (DESIGN section 5 candidate 2);
+  #   winpub = look-back window read a third of an iteration later, still ahead of the late prefetch (docs/rounds.md section 5 candidate 2);
   #   wg3 = HEAD held to 3 wavefronts per SIMD (f32 kernels): what the 4th workgroup per CU buys.   All checked bit-exact on the CPU
   #   beforehand (tools/variant_parity_cpu.py).  (A 128-work-item f32 tile -- two independent 2-wavefront pipelines -- is NOT rebuilt:
   #   round 1 measured one hypercube per 128-thread workgroup at 0.437 ms against 0.20: twice the tickets, descriptors, look-backs.)

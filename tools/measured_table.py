@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""After a GPU call of tools/gpu_batch.sh (first / explain): the "measured" cells of DESIGN.md section 5's predicted-vs-measured
+"""After a GPU call of tools/gpu_batch.sh (first / explain): the "measured" cells of DESIGN.md section 5c's predicted
 table, from the files the batch left in gpurun_out/ (or their copies in profiles/).  Prints markdown rows; nothing is written.
 usage: tools/measured_table.py <dir> <tag>        e.g. tools/measured_table.py gpurun_out r05a"""
 import json
