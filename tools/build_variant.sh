@@ -10,6 +10,7 @@
 #   -DNDZIP_EXP_COPYOUT_BATCH=n                copy-out: the LDS reads of n vectors per work-item issued back to back, one wait, then the stores
 #   -DNDZIP_PLAIN_INPUT_LOADS                  default cache policy instead of nt for the read-once input
 #   -DNDZIP_EXP_LINEAR_RUN64                   64-bit encoded runs linear in LDS (round-1 layout) instead of XOR-swizzled
+#   -DNDZIP_EXP_F64_NOCARRY                    64-bit stencil without borrow chains: x - y of two sums as x + ~y + 1 over v_lshl_add_u64 (variant f64sched)
 # e.g. tools/build_variant.sh knobs --lab -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION
 set -e
 name=$1; shift

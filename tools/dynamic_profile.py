@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--shape", default="32,64,64")
     ap.add_argument("--noise-mask", type=lambda s: int(s, 0), default=0xFF)
     ap.add_argument("--f64-work-items", type=int, default=0)
+    ap.add_argument("--lib", default=None, help="a variant library (ndzip_amd/_variants/<name>.so) instead of the product library")
     ap.add_argument("--scalar", action="store_true", help="also list every scalar-side opcode executed (SALU / waits / branches)")
     a = ap.parse_args()
     from ndzip_amd import hip, synth
@@ -53,7 +54,10 @@ def main():
     nhc = hip.num_hypercubes(shape)
     gx.PROFILE = collections.Counter()
     gx.LDS_PROFILE = collections.defaultdict(lambda: [0, 0, 0, 0])
-    bridge = gx.Bridge(simbuild.build(), [hip.LIB_PATH], tempfile.mkdtemp(prefix="gfx950_prof"))
+    if a.lib:  # (lab builds: the kernels take one more uint32, the experiment flags)
+        orig = gx.Bridge.kernel_named
+        gx.Bridge.kernel_named = lambda self, host_name: orig(self, host_name) or orig(self, host_name + "j")
+    bridge = gx.Bridge(simbuild.build(), [os.path.abspath(a.lib) if a.lib else hip.LIB_PATH], tempfile.mkdtemp(prefix="gfx950_prof"))
     with bridge:
         got = sim.compress(data, cus=4, blocks_per_cu=2)
         back = sim.decompress(want, dt, shape, f64_work_items=a.f64_work_items)
@@ -66,20 +70,20 @@ def main():
             continue
         per = collections.Counter()
         for (k, op), n in gx.PROFILE.items():
-            if k == name:
+            if k == name or k == name + "j":
                 per[klass(op)] += n
         short = name.split("N_1")[1][2:44]
         waves_per_hc = {True: 4, False: 2}["wide" in name] if "decompress" in name else (4 if "wide" in name else 2)
         valu = per["VALU"] / nhc
         print(f"{short:44s} grid {grid:3d} x {block}: " + "  ".join(f"{c} {per[c] / nhc:7.1f}" for c in ("VALU", "SALU", "LDS", "VMEM", "branch", "s_waitcnt", "s_nop", "s_barrier"))
               + f"  | per wavefront: VALU {valu / waves_per_hc:6.0f}  | VALU issue cycles per hypercube and SIMD (4 SIMDs share a hypercube's wavefronts): {valu * 4 / 4:6.0f}")
-        lds = [(op, r) for (k, op), r in gx.LDS_PROFILE.items() if k == name]
+        lds = [(op, r) for (k, op), r in gx.LDS_PROFILE.items() if k in (name, name + "j")]
         arr, ideal, busy = (sum(r[j] for _, r in lds) for j in (1, 2, 3))
         floor = sum(r[0] * gx._LDS_RULES[op][2] for op, r in lds)
         print(f"    LDS (the guide's lane groups and banks on the executed addresses): array cycles {arr / nhc:.0f} per hypercube, conflict-free {ideal / nhc:.0f}, "
               f"extra {(arr - ideal) / max(arr, 1):.1%} [SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE]; pipe busy {busy / nhc:.0f}, {floor / nhc:.0f} without conflicts; "
               + ", ".join(f"{op} {r[1] / max(r[2], 1):.2f}x" for op, r in sorted(lds, key=lambda kv: -(kv[1][1] - kv[1][2]))[:5]))
-        top = collections.Counter({op: n for (k, op), n in gx.PROFILE.items() if k == name})
+        top = collections.Counter({op: n for (k, op), n in gx.PROFILE.items() if k in (name, name + "j")})
         print("    top: " + ", ".join(f"{op} {n / nhc:.0f}" for op, n in top.most_common(14)))
         if a.scalar:
             print("    scalar side: " + ", ".join(f"{op} {n / nhc:.0f}" for op, n in top.most_common() if op.startswith("s_")))

@@ -22,6 +22,7 @@ wg3 -DNDZIP_EXP_DB_WAVES=3
 plainloads -DNDZIP_PLAIN_INPUT_LOADS
 timing -DNDZIP_EXP_KNOBS -DNDZIP_EXP_PHASE_TIMING
 knobs -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION
+f64sched -DNDZIP_EXP_F64_NOCARRY
 LIST
 python -c "from ndzip_amd import build; build.build_test_variants()"   # plain (no inline asm, no scalar pins), spin0
-python tools/variant_parity_cpu.py winpub trearly cobatch2 wg3 plainloads
+python tools/variant_parity_cpu.py winpub trearly cobatch2 wg3 plainloads f64sched

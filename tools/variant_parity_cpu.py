@@ -21,7 +21,8 @@ gx.Bridge.kernel_named = _named
 for v in sys.argv[1:]:
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ndzip_amd', '_variants', f'{v}.so')
     b = gx.Bridge(simbuild.build(), [lib], tempfile.mkdtemp(prefix='gfxv'))
-    for shape, dt in (((32, 32, 64), np.float32), ((16, 48, 32), np.float32), ((128, 192), np.float64), ((3*4096,), np.float32)):
+    for shape, dt in (((32, 32, 64), np.float32), ((16, 48, 32), np.float32), ((128, 192), np.float64), ((3*4096,), np.float32),
+                      ((16, 32, 48), np.float64), ((2*4096 + 9,), np.float64), ((70, 130), np.float64)):  # (every 64-bit stencil: the f64sched variant rewrites them)
         data = _mixed(shape, dt, 7)
         want = oracle.compress(data)
         with b:
