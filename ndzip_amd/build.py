@@ -150,7 +150,7 @@ def build_rccl(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(RCCL_OUT, deps):
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra", "-DNDZIP_HIP_BUILD", "-D__HIP_PLATFORM_AMD__",
                "-I" + os.path.join(ROCM, "include"), "-o", RCCL_OUT, *srcs, "-L" + HERE, "-lndzip_hip", "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lamdhip64",
-               "-Wl,-rpath,$ORIGIN", "-Wl,--no-undefined"]
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-Wl,--no-undefined"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)
