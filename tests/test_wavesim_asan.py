@@ -57,3 +57,19 @@ def test_the_sanitised_model_does_trap():
     # (the faulting frame by name or by source file: under a loaded machine the symbolizer has been seen to give up on names)
     assert any(k in r.stderr for k in ("copy_out", "copy_vectors", "codec_launch.inl", "libndzip_hip_wavesim_asan")), r.stderr[-3000:]
     assert "no trap" not in r.stdout
+
+
+def test_cpp_sharded_host_is_clean_under_address_sanitizer():
+    """ndzip_amd/csrc/sharded.cc (the C++ host of the multi-GPU path) sanitised and linked against the sanitised model: its buffers are
+    exactly as large as its plan says (header segment, body bound, gathered header), so an exchange, a compaction of unequal header
+    segments, a write_stream or a load that steps outside one traps.  One, two and three ranks (equal and unequal segments, a border)."""
+    from tests.wavesim import build as sb
+
+    env = asan_env()
+    sb.build_sharded(variant="asan")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_sharded_native_cpu.py", "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "reproduces_the_single_stream and (float32-2 or float64-3 or float64-1)"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "AddressSanitizer" not in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 4, tail

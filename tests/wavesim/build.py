@@ -104,24 +104,33 @@ def _build_locked(OUT, BUILD, FLAGS, verbose, extra_flags, kernel_flags) -> str:
     return OUT
 
 
-def build_sharded(force: bool = False, verbose: bool = False) -> str:
+def build_sharded(force: bool = False, verbose: bool = False, variant: str = None) -> str:
     """tests/wavesim/libndzip_hip_sharded_wavesim.so: the product's multi-GPU host (ndzip_amd/csrc/sharded.cc, unchanged; the RCCL file
     is left out -- the CPU tests supply the collectives table) compiled against the model's runtime header and linked against the model
-    library, so that include/ndzip_hip_sharded.h can be driven where there is no GPU."""
-    model = build()
-    out = os.path.join(HERE, "libndzip_hip_sharded_wavesim.so")
+    library, so that include/ndzip_hip_sharded.h can be driven where there is no GPU.  variant "asan" / "ubsan" (default: what
+    WAVESIM_VARIANT says, like sim.load): sharded.cc itself sanitised, linked against the sanitised model."""
+    if variant is None:
+        variant = os.environ.get("WAVESIM_VARIANT", "") if os.environ.get("WAVESIM_VARIANT") in ("asan", "ubsan") else ""
+    extra = ASAN_FLAGS if variant == "asan" else UBSAN_FLAGS if variant == "ubsan" else ()
+    model = build(variant=variant, extra_flags=extra)
+    out = os.path.join(HERE, f"libndzip_hip_sharded_wavesim{'_' + variant if variant else ''}.so")
     src = os.path.join(CSRC, "sharded.cc")
     deps = [src, model, os.path.join(ROOT, "include", "ndzip_hip.h"), os.path.join(ROOT, "include", "ndzip_hip_sharded.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
             os.path.abspath(__file__)]
-    if not force and os.path.exists(out) and all(os.path.getmtime(f) <= os.path.getmtime(out) for f in deps):
+
+    def fresh():
+        return os.path.exists(out) and all(os.path.getmtime(f) <= os.path.getmtime(out) for f in deps)
+
+    if not force and fresh():
         return out
-    with open(os.path.join(HERE, "_build", ".lock_sharded"), "w") as lock:
+    with open(os.path.join(HERE, "_build", f".lock_sharded_{variant or 'default'}"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and os.path.exists(out) and all(os.path.getmtime(f) <= os.path.getmtime(out) for f in deps):
+        if not force and fresh():
             return out
         tmp = out + f".tmp{os.getpid()}"
-        cmd = [CXX, *FLAGS, "-DNDZIP_HIP_BUILD", "-shared", "-I", HERE, "-o", tmp, src, "-L" + HERE, "-l:" + os.path.basename(model), "-Wl,-rpath,$ORIGIN",
-               "-Wl,--no-undefined"]
+        cmd = [CXX, *FLAGS, *extra, "-DNDZIP_HIP_BUILD", "-shared", "-I", HERE, "-o", tmp, src, "-L" + HERE, "-l:" + os.path.basename(model), "-Wl,-rpath,$ORIGIN"]
+        if not extra:
+            cmd.append("-Wl,--no-undefined")  # (a sanitised library leaves its runtime's symbols to the preloaded runtime)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)
