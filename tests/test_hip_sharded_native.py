@@ -20,9 +20,12 @@ LIBDIR = os.path.join(ROOT, "ndzip_amd")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
-def build_host(exe):
-    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
-                        "-I" + os.path.join(ROOT, "include"), SRC, "-o", str(exe), "-L" + LIBDIR, "-lndzip_hip_rccl", "-lndzip_hip",
+THREADS_SRC = os.path.join(ROOT, "tests", "cpp", "sharded_threads.cc")
+
+
+def build_host(exe, src=SRC):
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
+                        "-I" + os.path.join(ROOT, "include"), src, "-o", str(exe), "-L" + LIBDIR, "-lndzip_hip_rccl", "-lndzip_hip",
                         "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath," + os.path.join(ROCM, "lib")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -36,6 +39,10 @@ def test_example_host_compiles_and_links_against_the_sharded_library(tmp_path):
     # (rccl.h is not needed by a host that uses the bootstrap helpers: the program includes only the C ABI and the HIP runtime API)
     with open(SRC) as f:
         assert "rccl.h" not in f.read()
+
+
+def test_threads_host_compiles_and_links_against_the_sharded_library(tmp_path):
+    build_host(tmp_path / "sharded_threads", THREADS_SRC)
 
 
 def _gpus():
@@ -135,3 +142,29 @@ def test_native_codec_from_python_single_gpu(dtype, extent):
     assert np.array_equal(out.cpu().numpy().view(wdt), data.view(wdt))
     codec.close()
     back.close()
+
+
+THREAD_CASES = [(np.float32, (50, 37, 41), 3), (np.float64, (64 * 5 + 5, 130), 4), (np.float32, (6 * 4096 + 5,), 3), (np.float64, (32, 16, 48), 2),
+                (np.float32, (10, 70), 2), (np.float32, (128, 64, 64), 8)]
+
+
+def run_threads_host(tmp_path, exe, dtype, extent, world, env=None):
+    data = synth_numpy(extent, dtype, seed=9, noise_mask=0xFF)
+    (tmp_path / "in.bin").write_bytes(data.tobytes())
+    out = tmp_path / "stream.bin"
+    r = subprocess.run([exe, "--world", str(world), "--dtype", "f32" if np.dtype(dtype).itemsize == 4 else "f64", "--extent", ",".join(map(str, extent)),
+                        "--in", str(tmp_path / "in.bin"), "--out", str(out)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    want = oracle.compress(data)
+    got = np.fromfile(out, dtype=want.dtype)
+    assert len(got) == len(want) and np.array_equal(got, want), "the ranks' pieces do not add up to the reference stream"
+    assert r.stdout.count(": ok") == world
+
+
+@pytest.mark.gpu
+@pytest.mark.hardware_only
+@pytest.mark.parametrize("dtype,extent,world", THREAD_CASES)
+def test_threads_host_plays_every_rank_on_one_gpu(tmp_path, dtype, extent, world):
+    """The world > 1 path of the C++ host (length gather, offset kernel, padded header gather, compaction, layout, load) on a box with
+    ONE GPU: every rank a thread of tests/cpp/sharded_threads.cc, the exchange a rendezvous + device-to-device copies."""
+    run_threads_host(tmp_path, build_host(tmp_path / "sharded_threads", THREADS_SRC), dtype, extent, world)

@@ -203,3 +203,25 @@ def test_native_host_reproduces_the_single_stream_on_the_model_over_gloo(tmp_pat
         assert int(p["stream_words"]) == len(want)
         # exactly two collectives per compress: one uint32 per rank, then the longest header segment (none when nobody owns a hypercube)
         assert list(p["gathers"]) == ([] if world == 1 else [1, nmax] if nmax else [1, 1])
+
+
+def test_cpp_threads_host_on_the_model(tmp_path):
+    """tests/cpp/sharded_threads.cc -- every rank a thread of ONE C++ program, the exchange a caller-supplied table, no Python in the
+    loop -- compiled against the functional model: 2 / 3 / 4 / 8 ranks write the oracle's single stream and decode their slabs back
+    from it.  The same program runs on the GPU box in tests/test_hip_sharded_native.py."""
+    import subprocess
+
+    from tests.test_hip_sharded_native import THREAD_CASES, THREADS_SRC, run_threads_host
+    from tests.wavesim import build as simbuild
+
+    lib = simbuild.build_sharded(variant="")
+    here = os.path.dirname(lib)
+    exe = str(tmp_path / "sharded_threads_model")
+    r = subprocess.run([simbuild.CXX, "-std=c++17", "-O1", "-pthread", "-Wall", "-Wextra", "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-parameter",
+                        "-I", here, "-I", os.path.join(ROOT, "include"), THREADS_SRC, "-o", exe, "-L" + here, "-l:" + os.path.basename(lib),
+                        "-l:libndzip_hip_wavesim.so", "-Wl,-rpath," + here], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, WAVESIM_CUS="2", WAVESIM_BLOCKS_PER_CU="2")
+    env.pop("WAVESIM_VARIANT", None)
+    for dtype, extent, world in THREAD_CASES[:5]:
+        run_threads_host(tmp_path, exe, dtype, extent, world, env=env)
