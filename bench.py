@@ -497,11 +497,11 @@ def main(argv=None):
     # offsets and needs nothing from the other ranks (ndzip_amd/sharded.py: overlap_exchange) -- rehearsed over gloo on the
     # functional model and in tests/test_hip_sharded_rccl.py, opt-in until that test has passed on a multi-GPU node.
     if args.native_exchange:
-        if args.overlap_exchange or args.workgroups_per_cu or args.f64_work_items:
-            raise SystemExit("--native-exchange has no --overlap-exchange / --workgroups-per-cu / --f64-work-items (A/B handles of the Python driver)")
+        if args.workgroups_per_cu or args.f64_work_items:
+            raise SystemExit("--native-exchange has no --workgroups-per-cu / --f64-work-items (A/B handles of the Python driver)")
         from ndzip_amd import sharded_native
 
-        codec = sharded_native.NativeShardedCodec(np_dtype, global_extent, rank, world, device)
+        codec = sharded_native.NativeShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and args.overlap_exchange)
     else:
         codec = ShardedCodec(np_dtype, global_extent, rank, world, device, overlap_exchange=world > 1 and args.overlap_exchange)
     if args.workgroups_per_cu:

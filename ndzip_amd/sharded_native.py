@@ -159,7 +159,7 @@ class NativeShardedCodec:
     RCCL (then `comm` is ignored); `comm`: an existing ncclComm_t (integer) instead of bootstrapping one over `group`."""
 
     def __init__(self, dtype, global_extent: Sequence[int], rank: int, world: int, device, group=None, comm: Optional[int] = None,
-                 collectives: Optional[Collectives] = None):
+                 collectives: Optional[Collectives] = None, overlap_exchange: bool = False):
         import numpy as np
         import torch
 
@@ -170,6 +170,11 @@ class NativeShardedCodec:
         self.rank, self.world, self.device = rank, world, device
         self._own_comm = None
         self._collectives = collectives  # (kept alive: the C side calls through its function pointers)
+        # True: compress() is the codec launch alone; a decompress() that follows decodes the slab from its LOCAL offsets (it needs
+        # nothing from the other ranks) and the exchange is enqueued BEHIND the decode kernel; whoever asks for the layout, the
+        # stream or check() completes it first (the order ndzip_hip_sharded_compress_local / _decompress / _exchange of the C ABI)
+        self.overlap_exchange = overlap_exchange and world > 1
+        self._exchange_due = False
         stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
         h = C.c_void_p()
         if collectives is not None:
@@ -197,12 +202,22 @@ class NativeShardedCodec:
     def compress(self, local_in, kernel_events=None) -> None:
         """kernel_events: optional (start, stop) pair recorded tightly around the codec launch (the exchange follows it)."""
         L = lib()
+        self.finish()  # (one exchange per compress_local)
         if kernel_events:
             kernel_events[0].record()
         _check(L.ndzip_hip_sharded_compress_local(self._h, hip._ptr(local_in)))
         if kernel_events:
             kernel_events[1].record()
-        _check(L.ndzip_hip_sharded_exchange(self._h))
+        if self.overlap_exchange:
+            self._exchange_due = True
+        else:
+            _check(L.ndzip_hip_sharded_exchange(self._h))
+
+    def finish(self) -> None:
+        """The exchange of the last compress(), if it was left for later."""
+        if self._exchange_due:
+            self._exchange_due = False
+            _check(lib().ndzip_hip_sharded_exchange(self._h))
 
     def decompress(self, local_out, kernel_events=None) -> None:
         if kernel_events:
@@ -210,13 +225,16 @@ class NativeShardedCodec:
         _check(lib().ndzip_hip_sharded_decompress(self._h, hip._ptr(local_out)))
         if kernel_events:
             kernel_events[1].record()
+        self.finish()  # (overlapped mode: ... and continues behind the decode kernel)
 
     def check(self) -> None:
+        self.finish()
         _check(lib().ndzip_hip_sharded_check(self._h))
 
     # ---- results ---------------------------------------------------------------------------------------------------
     def pointers(self):
         """(d_header_global, num_entries, d_body, d_body_length_words, d_base_words) as integers."""
+        self.finish()
         hp, n = C.c_void_p(), C.c_uint32()
         _check(lib().ndzip_hip_sharded_header_global(self._h, C.byref(hp), C.byref(n)))
         b, bl, ba = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -225,6 +243,7 @@ class NativeShardedCodec:
 
     def stream_layout(self) -> StreamLayout:
         lay = StreamLayout()
+        self.finish()
         _check(lib().ndzip_hip_sharded_stream_layout(self._h, C.byref(lay)))
         return lay
 

@@ -112,7 +112,7 @@ def native_case(args, i, dtype, extent, full, wdt, rank, world, device):
         sharded_native._lib = sharded_native._bind(C.CDLL(simbuild.build_sharded()), rccl=False)
         table, _ = _gloo_table(world)
         kw["collectives"] = table
-    codec = sharded_native.NativeShardedCodec(dtype, extent, rank, world, device, **kw)
+    codec = sharded_native.NativeShardedCodec(dtype, extent, rank, world, device, overlap_exchange=args.overlap_exchange, **kw)
     sh = codec.shard
     slab = torch.from_numpy(np.ascontiguousarray(full[sh.start0: sh.start0 + sh.extent[0]])).to(device)
     out = torch.zeros_like(slab)

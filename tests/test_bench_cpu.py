@@ -179,7 +179,7 @@ def test_native_exchange_single_rank_on_the_model(monkeypatch, capsys):
     with sim.active():
         bench.main(["--shape", "130,200", "--dtype", "float64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--native-exchange"])
         with pytest.raises(SystemExit, match="--native-exchange has no"):
-            bench.main(["--shape", "32,32,32", "--native-exchange", "--workgroups-per-cu", "2"])
+            bench.main(["--shape", "32,32,32", "--native-exchange", "--workgroups-per-cu", "2"])  # (an A/B handle of the Python driver)
     d = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
     assert d["roundtrip_bit_exact"] is True and d["n_gpus"] == 1 and d["config"]["host"].startswith("C++ (libndzip_hip_rccl.so")
     # the same workload through the Python driver: same stream length, hence the same ratio
@@ -249,7 +249,7 @@ def test_main_with_two_ranks_over_gloo_on_the_model(tmp_path):
     assert d["config"]["hypercubes"] == 2 * 8 and "64x32x32" in d["config"]["workload"] and "2 z-slab(s) of 32x32x32" in d["config"]["workload"]
 
 
-@pytest.mark.parametrize("extra", [[], ["--native-exchange"]], ids=["python-driver", "cpp-host"])
+@pytest.mark.parametrize("extra", [[], ["--native-exchange"], ["--native-exchange", "--overlap-exchange"]], ids=["python-driver", "cpp-host", "cpp-host-overlap"])
 def test_gpus_2_typed_as_is_starts_its_own_ranks(tmp_path, extra):
     """`python bench.py --gpus 2 ...` with NO RANK / WORLD_SIZE in the environment (what the driver's single-command form and a
     user at a shell type): bench.py starts the two ranks itself under torch.distributed.run, stdout carries exactly rank 0's

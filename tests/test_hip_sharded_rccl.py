@@ -84,8 +84,8 @@ def check_against_oracle(world, out_dir, cases):
 @pytest.mark.gpu
 @pytest.mark.hardware_only
 @pytest.mark.skipif(_gpus() < 2, reason="needs at least 2 GPUs (one process per GPU over RCCL)")
-@pytest.mark.parametrize("mode", [[], ["--async-header-gather"], ["--overlap-exchange"], ["--native"]],
-                         ids=["sync-header-gather", "async-header-gather", "overlap-exchange", "native-cpp-host"])
+@pytest.mark.parametrize("mode", [[], ["--async-header-gather"], ["--overlap-exchange"], ["--native"], ["--native", "--overlap-exchange"]],
+                         ids=["sync-header-gather", "async-header-gather", "overlap-exchange", "native-cpp-host", "native-cpp-host-overlap"])
 def test_all_gpus_over_rccl_reproduce_the_single_stream(tmp_path, mode):
     world = _gpus()
     cases = cases_for(world)

@@ -155,8 +155,8 @@ def test_sharded_codec_on_the_model_over_gloo(tmp_path, extent, dtype, world, as
 
 
 @pytest.mark.parametrize("world,mode", [(2, []), (3, ["--async-header-gather"]), (2, ["--overlap-exchange"]), (3, ["--overlap-exchange"]),
-                                        (2, ["--native"]), (3, ["--native"])],
-                         ids=["2-sync", "3-async-header", "2-overlap", "3-overlap", "2-native", "3-native"])
+                                        (2, ["--native"]), (3, ["--native"]), (3, ["--native", "--overlap-exchange"])],
+                         ids=["2-sync", "3-async-header", "2-overlap", "3-overlap", "2-native", "3-native", "3-native-overlap"])
 def test_rccl_parity_harness_rehearsed_over_gloo_on_the_model(tmp_path, world, mode):
     """tests/test_hip_sharded_rccl.py's harness -- torch.distributed.run, tests/mp/sharded_rank_main.py, assembly, oracle
     comparison -- with backend gloo and the kernels on the functional model: what runs on the first multi-GPU node is this,

@@ -46,6 +46,9 @@ first)
   cp gpurun_out/traffic.json profiles/traffic.json 2>/dev/null
   timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
   cat ${O}_bench_n1.json; tail -5 ${O}_bench_n1.err
+  # the same step through the C++ host of the sharded path (libndzip_hip_rccl.so; one shard at N = 1: no communicator) -- its first time on silicon
+  (timeout 200 python bench.py --native-exchange --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -2) > ${O}_bench_n1_native.txt
+  cat ${O}_bench_n1_native.txt
   (timeout 700 bash tools/bench_configs.sh 2>&1) > ${O}_configs.txt
   cat ${O}_configs.txt
   # rocprofv3 --kernel-trace --stats of the other two single-GPU headline configurations (cfg 3; cfg 5's rank slab, both f64 decoders):
@@ -119,7 +122,7 @@ poll)
   ;;
 collect)
   dst=${3:-$tag}
-  for f in rocminfo smoke gputest variant_parity bench_n1.json configs kernel_times_f64 workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d \
+  for f in rocminfo smoke gputest variant_parity bench_n1.json bench_n1_native configs kernel_times_f64 workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d \
            rocprofv3_summary_f64_3d_decode_256 rocprofv3_summary_f64_3d_decode_128 ab_variants ab_variants_cfg1 ab_variants_f64_2d \
            ab_variants_f64_3d phase_timing two_process_stress; do
     for ext in "" .txt; do
