@@ -225,3 +225,67 @@ def test_cpp_threads_host_on_the_model(tmp_path):
     env.pop("WAVESIM_VARIANT", None)
     for dtype, extent, world in THREAD_CASES[:5]:
         run_threads_host(tmp_path, exe, dtype, extent, world, env=env)
+
+
+def test_misuse_and_corrupt_streams_are_refused_on_the_model(monkeypatch):
+    """The handle's state rules and the host-side validation of ndzip_hip_sharded_load, on one shard of the model: decode before
+    anything was compressed or loaded, layout / write_stream while the exchange is still due, a stream buffer that is too small, a
+    truncated stream, a header entry out of order, a stream of another extent -- every one an error code with a message, none a
+    wild read."""
+    from tests.wavesim import build as simbuild
+    from tests.wavesim import sim
+
+    monkeypatch.setattr(sharded_native, "_lib", sharded_native._bind(C.CDLL(simbuild.build_sharded(variant="")), rccl=False))
+    L = sharded_native.lib()
+
+    @sharded_native.ALL_GATHER_U32
+    def never(ctx, send, recv, count, stream):
+        return 1
+
+    table = sharded_native.Collectives(None, never, sharded_native.ERROR_STRING())
+    extent, dtype = (130, 200), np.float64
+    data = synth_numpy(extent, dtype, seed=3, noise_mask=0xFF)
+    want = oracle.compress(data)
+    import torch
+
+    with sim.active():
+        codec = sharded_native.NativeShardedCodec(dtype, extent, 0, 1, torch.device("cpu"), collectives=table)
+        out = np.zeros_like(data)
+        with pytest.raises(hip.NdzipHipError, match="nothing to decode"):
+            codec.decompress(out.ctypes.data)
+        with pytest.raises(hip.NdzipHipError, match="no stream"):
+            codec.stream_layout()
+        sharded_native._check(L.ndzip_hip_sharded_compress_local(codec._h, data.ctypes.data))
+        with pytest.raises(hip.NdzipHipError, match="still local"):
+            codec.stream_layout()
+        with pytest.raises(hip.NdzipHipError, match="still local"):
+            codec.write_stream(np.zeros(len(want), dtype=want.dtype), with_header=True)
+        codec.decompress(out.ctypes.data)  # (allowed: the slab decodes from its local offsets)
+        assert np.array_equal(out.view(np.uint64), data.view(np.uint64))
+        sharded_native._check(L.ndzip_hip_sharded_exchange(codec._h))
+        with pytest.raises(hip.NdzipHipError) as e:
+            codec.write_stream(np.zeros(len(want) - 1, dtype=want.dtype), with_header=True)
+        assert e.value.status == -3 and "the buffer" in str(e.value)  # NDZIP_HIP_ERR_CAPACITY
+        got = np.zeros(len(want), dtype=want.dtype)
+        codec.write_stream(got, with_header=True)
+        assert np.array_equal(got, want)
+        # the way back refuses what is not a stream of THIS extent
+        back = sharded_native.NativeShardedCodec(dtype, extent, 0, 1, torch.device("cpu"), collectives=table)
+        with pytest.raises(hip.NdzipHipError):
+            back.load(want[: len(want) - 5])                      # truncated
+        bad = want.copy()
+        bad.view(np.uint32)[1] = bad.view(np.uint32)[0]            # second entry does not follow the first by a hypercube's length
+        with pytest.raises(hip.NdzipHipError):
+            back.load(bad)
+        other = oracle.compress(synth_numpy((70, 200), dtype, seed=3, noise_mask=0xFF))
+        with pytest.raises(hip.NdzipHipError):
+            back.load(other)                                       # fewer hypercubes than this extent's header needs
+        with pytest.raises(hip.NdzipHipError, match="nothing to decode"):
+            back.decompress(out.ctypes.data)                       # (a refused load leaves the handle empty)
+        back.load(want)
+        out[:] = 0
+        back.decompress(out.ctypes.data)
+        back.check()
+        assert np.array_equal(out.view(np.uint64), data.view(np.uint64))
+        codec.close()
+        back.close()
