@@ -168,3 +168,12 @@ def test_threads_host_plays_every_rank_on_one_gpu(tmp_path, dtype, extent, world
     """The world > 1 path of the C++ host (length gather, offset kernel, padded header gather, compaction, layout, load) on a box with
     ONE GPU: every rank a thread of tests/cpp/sharded_threads.cc, the exchange a rendezvous + device-to-device copies."""
     run_threads_host(tmp_path, build_host(tmp_path / "sharded_threads", THREADS_SRC), dtype, extent, world)
+
+
+@pytest.mark.gpu
+@pytest.mark.hardware_only
+def test_cpp_adaptor_of_the_sharded_path_on_gpu(tmp_path):
+    """include/ndzip_hip_sharded.hh through tests/cpp/sharded_adaptor_roundtrip.cc against the real library (one shard)."""
+    from tests.test_sharded_native_cpu import ADAPTOR_SRC, run_adaptor_program
+
+    run_adaptor_program(tmp_path, build_host(tmp_path / "sharded_adaptor", ADAPTOR_SRC))

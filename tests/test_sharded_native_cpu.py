@@ -289,3 +289,46 @@ def test_misuse_and_corrupt_streams_are_refused_on_the_model(monkeypatch):
         assert np.array_equal(out.view(np.uint64), data.view(np.uint64))
         codec.close()
         back.close()
+
+
+ADAPTOR_SRC = os.path.join(ROOT, "tests", "cpp", "sharded_adaptor_roundtrip.cc")
+ADAPTOR_CASES = [(np.float32, (50, 37, 41)), (np.float64, (130, 200)), (np.float64, (3 * 4096 + 5,)), (np.float32, (10, 70))]
+
+
+def run_adaptor_program(tmp_path, exe, env=None):
+    import subprocess
+
+    for dtype, extent in ADAPTOR_CASES:
+        data = synth_numpy(extent, dtype, seed=9, noise_mask=0xFF)
+        (tmp_path / "in.bin").write_bytes(data.tobytes())
+        (tmp_path / "ref.bin").write_bytes(oracle.compress(data).tobytes())
+        r = subprocess.run([exe, "f32" if np.dtype(dtype).itemsize == 4 else "f64", ",".join(map(str, extent)), str(tmp_path / "in.bin"), str(tmp_path / "ref.bin")],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "round trip ok" in r.stdout, (extent, r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_cpp_adaptor_of_the_sharded_path_on_the_model(tmp_path):
+    """include/ndzip_hip_sharded.hh (hip_sharded_codec<T>, the <T, Dims> spelling, exceptions with the C ABI's message) through
+    tests/cpp/sharded_adaptor_roundtrip.cc on the functional model: stream == the oracle's, both ways back -- and the header compiles
+    against the real HIP headers and, where the reference tree exists, against the reference's own ndzip.hh (its extent type)."""
+    import subprocess
+
+    from tests.wavesim import build as simbuild
+
+    lib = simbuild.build_sharded(variant="")
+    here = os.path.dirname(lib)
+    exe = str(tmp_path / "sharded_adaptor_model")
+    r = subprocess.run([simbuild.CXX, "-std=c++17", "-O1", "-pthread", "-Wall", "-Wextra", "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-parameter",
+                        "-I", here, "-I", os.path.join(ROOT, "include"), ADAPTOR_SRC, "-o", exe, "-L" + here, "-l:" + os.path.basename(lib),
+                        "-l:libndzip_hip_wavesim.so", "-Wl,-rpath," + here], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, WAVESIM_CUS="2", WAVESIM_BLOCKS_PER_CU="2")
+    env.pop("WAVESIM_VARIANT", None)
+    run_adaptor_program(tmp_path, exe, env)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    base = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(ROOT, "include")]
+    r = subprocess.run(base + [ADAPTOR_SRC], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    if os.path.isdir("/root/reference/include/ndzip"):
+        r = subprocess.run(base[:4] + base[5:] + ["-DNDZIP_HIP_WITH_REFERENCE_HEADERS", "-I/root/reference/include", ADAPTOR_SRC], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
