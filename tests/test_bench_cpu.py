@@ -142,6 +142,7 @@ def test_main_produces_the_contract_line_on_the_model(monkeypatch, capsys, argv,
                 "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["ranks"] == {"world_size": 1, "backend": None, "device_ids": [0], "launched_by": "python"} and d["config"]["host"].startswith("Python")
     # (the model is ~10^5 times slower than the GPU: the rounded GB/s figure may well be 0.0 here)
     assert d["unit"] == "GB/s" and d["value"] >= 0 and d["ms_per_step"] > 0 and d["scaling"] == "weak" and d["roundtrip_bit_exact"] is True
     assert set(d["config"]) >= {"workload", "hypercubes", "compression_ratio", "step"} and "model" not in d["config"]
