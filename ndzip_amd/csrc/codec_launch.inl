@@ -116,8 +116,12 @@ NDZIP_DEV uint32_t launch_epoch_load(const uint32_t *tickets) {
     return __hip_atomic_load(tickets + epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 NDZIP_DEV uint32_t launch_epoch(uint32_t loaded) { return static_cast<uint32_t>(wave_uniform(static_cast<int>(loaded))); }
-// (`tid`: work-item id in a one-dimensional workgroup of at least 64; every work-item of the workgroup calls this)
+// (`tid`: work-item id in a one-dimensional workgroup of WorkItems; EVERY work-item of the workgroup calls this, from converged code:
+// wavefront 0 reads lane 0's verdict with a shuffle and wipes in strides of 64, so all of its 64 lanes have to be there.  The
+// workgroup size is a template argument so that the contract is checked where a kernel instantiates it, not in a comment.)
+template<int WorkItems>
 NDZIP_DEV void release_tickets(uint32_t *tickets, uint32_t num_classes, int tid, uint32_t *err, uint32_t *out_len, desc_ref desc) {
+    static_assert(WorkItems >= 64 && WorkItems % 64 == 0, "release_tickets: wavefront 0 must be a full wavefront (whole wavefronts per workgroup)");
     if (tid >= 64) return;  // wavefront 0 stays together: its 64 lanes share the wipe below, work-item 0 does everything else
     uint32_t *done = tickets + ticket_classes * ticket_stride_words;
     uint32_t last = 0;
@@ -593,7 +597,7 @@ compress_kernel_db(const typename word_of<T>::type *__restrict__ in, const grid_
     }
     // The last workgroup to leave zeroes the ticket counters for the next launch on this handle (stream order makes it
     // visible); the descriptors need no clearing (epoch).
-    release_tickets(tickets, num_classes, tid, err, out_len, desc);
+    release_tickets<C::threads>(tickets, num_classes, tid, err, out_len, desc);
 }
 
 // ---- the register-buffered deferred-write-out pipeline with 256 work-items per hypercube ("wide" mapping) ---------
@@ -744,7 +748,7 @@ compress_kernel_wide(const W *__restrict__ in, const grid_geom gg, uint32_t *__r
             }
         }
     }
-    release_tickets(tickets, num_classes, tid, err, out_len, desc);
+    release_tickets<C::threads>(tickets, num_classes, tid, err, out_len, desc);
 }
 
 template<typename T, int Dims, bool Aligned>
@@ -1112,7 +1116,7 @@ debug_lookback_kernel(const uint32_t *__restrict__ lengths, uint32_t *__restrict
         prev_aggregate = aggregate;
         tile = next_tile;
     }
-    release_tickets(tickets, num_classes, lane, err, total, desc);
+    release_tickets<64>(tickets, num_classes, lane, err, total, desc);
 }
 
 #endif  // NDZIP_STAGE_KERNELS
