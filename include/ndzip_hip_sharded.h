@@ -80,6 +80,23 @@ NDZIP_HIP_API int ndzip_hip_sharded_create(int dtype, int dims, const uint32_t *
 NDZIP_HIP_API int ndzip_hip_sharded_create_with_collectives(int dtype, int dims, const uint32_t *global_extent, uint32_t rank, uint32_t world,
         const ndzip_hip_collectives *collectives, void *hip_stream, ndzip_hip_sharded **out);
 
+/* ---- in-process rank group: every rank a THREAD of one process ---------------------------------------------------------------
+ * For a single process that drives several GPUs (one thread per GPU) -- or several ranks on one GPU -- without RCCL: the all-gather
+ * is a rendezvous of the group's threads followed by device-to-device copies on each rank's own stream (peer copies over xGMI
+ * between GPUs).  Rank r's thread selects its device, creates its handle with ndzip_hip_sharded_create_local and then calls the
+ * same entry points as any other rank; all ranks must reach each ndzip_hip_sharded_compress / _exchange (a collective). */
+typedef struct ndzip_hip_local_group ndzip_hip_local_group;
+NDZIP_HIP_API int ndzip_hip_local_group_create(uint32_t world, ndzip_hip_local_group **out);
+NDZIP_HIP_API int ndzip_hip_local_group_destroy(ndzip_hip_local_group *group);
+/* a barrier of the group's `world` threads (for the host's own hand-offs: "every rank has written its pieces") */
+NDZIP_HIP_API int ndzip_hip_local_group_barrier(ndzip_hip_local_group *group);
+NDZIP_HIP_API int ndzip_hip_sharded_create_local(int dtype, int dims, const uint32_t *global_extent, uint32_t rank, uint32_t world,
+        ndzip_hip_local_group *group, void *hip_stream, ndzip_hip_sharded **out);
+
+/* hipGetDeviceCount / hipSetDevice for a host that includes no HIP header (the calling thread's current device) */
+NDZIP_HIP_API int ndzip_hip_sharded_device_count(int *count);
+NDZIP_HIP_API int ndzip_hip_sharded_set_device(int device);
+
 /* Bootstrap helpers for a host that does not want rccl.h itself: ncclGetUniqueId (rank 0; send the 128 bytes to the other
  * ranks by any means), ncclCommInitRank (every rank, after hipSetDevice), ncclCommDestroy. */
 #define NDZIP_HIP_RCCL_UNIQUE_ID_BYTES 128
@@ -102,6 +119,14 @@ NDZIP_HIP_API int ndzip_hip_sharded_exchange(ndzip_hip_sharded *s);
 
 /* Decodes this rank's slab from what the last compress left (or ndzip_hip_sharded_load put) in the handle.  No collective. */
 NDZIP_HIP_API int ndzip_hip_sharded_decompress(ndzip_hip_sharded *s, void *d_out_slab);
+
+/* Host-pointer forms (what offloader<T> is to cuda_compressor<T>, include/ndzip/offload.hh:8-34): the slab is copied to / from a
+ * device buffer the handle owns (allocated on first use).  compress_host copies in with hipMemcpyAsync (which returns early only for pinned memory: the
+ * runtime's rule) and enqueues codec launch and exchange behind it; decompress_host returns when the slab is in `host_slab`. */
+NDZIP_HIP_API int ndzip_hip_sharded_compress_host(ndzip_hip_sharded *s, const void *host_slab);
+/* copy-in + ndzip_hip_sharded_compress_local: ndzip_hip_sharded_exchange is the caller's next step */
+NDZIP_HIP_API int ndzip_hip_sharded_compress_local_host(ndzip_hip_sharded *s, const void *host_slab);
+NDZIP_HIP_API int ndzip_hip_sharded_decompress_host(ndzip_hip_sharded *s, void *host_slab);
 
 /* Device-resident results of the last compress: all num_hypercubes(global extent) header entries with global offsets ... */
 NDZIP_HIP_API int ndzip_hip_sharded_header_global(const ndzip_hip_sharded *s, const uint32_t **d_header, uint32_t *num_entries);

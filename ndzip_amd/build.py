@@ -139,6 +139,8 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
 
 RCCL_OUT = os.path.join(HERE, "libndzip_hip_rccl.so")
 RCCL_SOURCES = ["sharded.cc", "sharded_rccl.cc"]
+SHARDED_CLI_OUT = os.path.join(HERE, "ndzip-hip-sharded")
+SHARDED_CLI_SRC = os.path.join(HERE, "cli", "ndzip_hip_sharded_cli.cc")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
@@ -151,6 +153,15 @@ def build_rccl(force: bool = False, verbose: bool = False) -> str:
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra", "-DNDZIP_HIP_BUILD", "-D__HIP_PLATFORM_AMD__",
                "-I" + os.path.join(ROCM, "include"), "-o", RCCL_OUT, *srcs, "-L" + HERE, "-lndzip_hip", "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lamdhip64",
                "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-Wl,--no-undefined"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    # ndzip_amd/ndzip-hip-sharded: the file-level tool of the multi-GPU path (plain C++ over include/ndzip_hip_sharded.h, no HIP header)
+    if force or _stale(SHARDED_CLI_OUT, [SHARDED_CLI_SRC, RCCL_OUT, os.path.join(HERE, "..", "include", "ndzip_hip_sharded.h")]):
+        cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-Wall", "-Wextra", "-o", SHARDED_CLI_OUT, SHARDED_CLI_SRC, "-L" + HERE, "-lndzip_hip_rccl", "-lndzip_hip",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)

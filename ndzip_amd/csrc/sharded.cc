@@ -7,9 +7,12 @@
 // The RCCL table and the ncclComm_t constructor are in sharded_rccl.cc.
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -101,7 +104,35 @@ int plan(int dtype, int dims, const uint32_t *extent, uint32_t rank, uint32_t wo
 
 }  // namespace
 
+// The in-process transport: the ranks are threads, the all-gather a rendezvous + device-to-device copies (see the header).
+struct ndzip_hip_local_group {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t world = 1, arrived = 0, generation = 0;
+    std::vector<const uint32_t *> send;
+    void wait() {  // reusable barrier
+        std::unique_lock<std::mutex> l(m);
+        const uint32_t g = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(l, [&] { return generation != g; });
+        }
+    }
+};
+
+namespace {
+struct local_rank {
+    ndzip_hip_local_group *group;
+    uint32_t rank;
+};
+}  // namespace
+
 struct ndzip_hip_sharded {
+    std::unique_ptr<local_rank> local;  // create_local: the table's context, owned by the handle
+    void *slab_dev = nullptr;            // compress_host / decompress_host: the slab on the device (first use)
     int dtype = 0, dims = 0;
     uint32_t extent[3] = {0, 0, 0};
     uint32_t rank = 0, world = 1;
@@ -134,6 +165,7 @@ struct ndzip_hip_sharded {
             if (p) (void) hipFree(p);
         }
         if (header_global && header_global != header_gathered && header_global != header_local) (void) hipFree(header_global);
+        if (slab_dev) (void) hipFree(slab_dev);
     }
 };
 
@@ -244,9 +276,113 @@ int create(int dtype, int dims, const uint32_t *global_extent, uint32_t rank, ui
     return NDZIP_HIP_OK;
 }
 
+// stream-ordered on the CALLER's stream as the table's contract says: the send buffer is complete when that stream has drained
+int local_all_gather_u32(void *ctx, const uint32_t *d_send, uint32_t *d_recv, size_t count, void *hip_stream) {
+    auto *c = static_cast<local_rank *>(ctx);
+    auto stream = static_cast<hipStream_t>(hip_stream);
+    if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+    c->group->send[c->rank] = d_send;
+    c->group->wait();
+    int rc = 0;
+    for (uint32_t r = 0; r < c->group->world && rc == 0; ++r) {
+        if (hipMemcpyAsync(d_recv + r * count, c->group->send[r], count * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream) != hipSuccess) rc = 2;
+    }
+    if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess) rc = 3;
+    c->group->wait();  // nobody overwrites its send buffer before everybody has read it (reached even on an error: no rank is left waiting)
+    return rc;
+}
+
+const char *local_error_string(void *, int code) {
+    return code == 1 ? "the rank's stream did not drain" : code == 2 ? "device-to-device copy failed" : "the copies did not complete";
+}
+
+size_t slab_bytes(const ndzip_hip_sharded *s) {
+    size_t n = word_bytes(s->dtype);
+    for (int d = 0; d < s->dims; ++d) n *= s->shard.extent[d];
+    return n;
+}
+
+int ensure_slab(ndzip_hip_sharded *s) {
+    if (s->slab_dev) return NDZIP_HIP_OK;
+    const size_t n = slab_bytes(s);
+    HIP_TRY(hipMalloc(&s->slab_dev, n ? n : 1), "slab staging buffer");
+    return NDZIP_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+NDZIP_HIP_API int ndzip_hip_local_group_create(uint32_t world, ndzip_hip_local_group **out) {
+    if (!out || world == 0) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null group pointer or an empty group");
+    auto *g = new (std::nothrow) ndzip_hip_local_group;
+    if (!g) return fail(NDZIP_HIP_ERR_RUNTIME, "out of host memory");
+    g->world = world;
+    g->send.assign(world, nullptr);
+    *out = g;
+    return NDZIP_HIP_OK;
+}
+
+NDZIP_HIP_API int ndzip_hip_local_group_destroy(ndzip_hip_local_group *group) {
+    delete group;
+    return NDZIP_HIP_OK;
+}
+
+NDZIP_HIP_API int ndzip_hip_local_group_barrier(ndzip_hip_local_group *group) {
+    if (!group) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null group");
+    group->wait();
+    return NDZIP_HIP_OK;
+}
+
+NDZIP_HIP_API int ndzip_hip_sharded_create_local(int dtype, int dims, const uint32_t *global_extent, uint32_t rank, uint32_t world,
+        ndzip_hip_local_group *group, void *hip_stream, ndzip_hip_sharded **out) {
+    if (out) *out = nullptr;
+    if (!group) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null group");
+    if (group->world != world) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "the group has %u ranks, the plan %u", group->world, world);
+    std::unique_ptr<local_rank> ctx(new (std::nothrow) local_rank{group, rank});
+    if (!ctx) return fail(NDZIP_HIP_ERR_RUNTIME, "out of host memory");
+    const ndzip_hip_collectives table{ctx.get(), local_all_gather_u32, local_error_string};
+    if (int st = create(dtype, dims, global_extent, rank, world, &table, hip_stream, out)) return st;
+    (*out)->local = std::move(ctx);
+    return NDZIP_HIP_OK;
+}
+
+NDZIP_HIP_API int ndzip_hip_sharded_device_count(int *count) {
+    if (!count) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *count = 0;
+    if (hipGetDeviceCount(count) != hipSuccess || *count <= 0) return fail(NDZIP_HIP_ERR_NO_DEVICE, "no GPU visible (this back-end has no CPU fallback)");
+    return NDZIP_HIP_OK;
+}
+
+NDZIP_HIP_API int ndzip_hip_sharded_set_device(int device) {
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    return NDZIP_HIP_OK;
+}
+
+NDZIP_HIP_API int ndzip_hip_sharded_compress_local_host(ndzip_hip_sharded *s, const void *host_slab) {
+    if (!s) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle");
+    const size_t n = slab_bytes(s);
+    if (!host_slab && n) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null slab");
+    if (int st = ensure_slab(s)) return st;
+    if (n) HIP_TRY(hipMemcpyAsync(s->slab_dev, host_slab, n, hipMemcpyHostToDevice, s->stream), "copying the slab to the device");
+    return ndzip_hip_sharded_compress_local(s, s->slab_dev);
+}
+
+NDZIP_HIP_API int ndzip_hip_sharded_compress_host(ndzip_hip_sharded *s, const void *host_slab) {
+    if (int st = ndzip_hip_sharded_compress_local_host(s, host_slab)) return st;
+    return ndzip_hip_sharded_exchange(s);
+}
+
+NDZIP_HIP_API int ndzip_hip_sharded_decompress_host(ndzip_hip_sharded *s, void *host_slab) {
+    if (!s) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null handle");
+    const size_t n = slab_bytes(s);
+    if (!host_slab && n) return fail(NDZIP_HIP_ERR_INVALID_ARGUMENT, "null slab");
+    if (int st = ensure_slab(s)) return st;
+    if (int st = ndzip_hip_sharded_decompress(s, s->slab_dev)) return st;
+    if (n) HIP_TRY(hipMemcpyAsync(host_slab, s->slab_dev, n, hipMemcpyDeviceToHost, s->stream), "copying the slab to the host");
+    HIP_TRY(hipStreamSynchronize(s->stream), "copying the slab to the host");
+    return NDZIP_HIP_OK;
+}
 
 NDZIP_HIP_API int ndzip_hip_sharded_abi_version(void) { return NDZIP_HIP_SHARDED_ABI_VERSION; }
 

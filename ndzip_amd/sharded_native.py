@@ -28,6 +28,15 @@ EXPORTED_SYMBOLS = (
     "ndzip_hip_rccl_unique_id",
     "ndzip_hip_rccl_comm_create",
     "ndzip_hip_rccl_comm_destroy",
+    "ndzip_hip_local_group_create",
+    "ndzip_hip_local_group_destroy",
+    "ndzip_hip_local_group_barrier",
+    "ndzip_hip_sharded_create_local",
+    "ndzip_hip_sharded_device_count",
+    "ndzip_hip_sharded_set_device",
+    "ndzip_hip_sharded_compress_host",
+    "ndzip_hip_sharded_compress_local_host",
+    "ndzip_hip_sharded_decompress_host",
     "ndzip_hip_sharded_shard",
     "ndzip_hip_sharded_compress",
     "ndzip_hip_sharded_compress_local",
@@ -78,6 +87,15 @@ def _bind(L, rccl: bool = True):
     sig = {
         "ndzip_hip_sharded_plan": [C.c_int, C.c_int, u32p, C.c_uint32, C.c_uint32, C.POINTER(Shard)],
         "ndzip_hip_sharded_create_with_collectives": [C.c_int, C.c_int, u32p, C.c_uint32, C.c_uint32, C.POINTER(Collectives), vp, C.POINTER(vp)],
+        "ndzip_hip_local_group_create": [C.c_uint32, C.POINTER(vp)],
+        "ndzip_hip_local_group_destroy": [vp],
+        "ndzip_hip_local_group_barrier": [vp],
+        "ndzip_hip_sharded_create_local": [C.c_int, C.c_int, u32p, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(vp)],
+        "ndzip_hip_sharded_device_count": [C.POINTER(C.c_int)],
+        "ndzip_hip_sharded_set_device": [C.c_int],
+        "ndzip_hip_sharded_compress_host": [vp, vp],
+        "ndzip_hip_sharded_compress_local_host": [vp, vp],
+        "ndzip_hip_sharded_decompress_host": [vp, vp],
         "ndzip_hip_sharded_shard": [vp, C.POINTER(Shard)],
         "ndzip_hip_sharded_compress": [vp, vp],
         "ndzip_hip_sharded_compress_local": [vp, vp],

@@ -177,3 +177,45 @@ def test_cpp_adaptor_of_the_sharded_path_on_gpu(tmp_path):
     from tests.test_sharded_native_cpu import ADAPTOR_SRC, run_adaptor_program
 
     run_adaptor_program(tmp_path, build_host(tmp_path / "sharded_adaptor", ADAPTOR_SRC))
+
+
+def _run_tool(tmp_path, dtype, extent, extra, expect):
+    """ndzip_amd/ndzip-hip-sharded on the GPU: the stream file == the oracle's stream of the whole array; a reference stream decodes
+    back to the array."""
+    from ndzip_amd import build
+
+    exe = build.SHARDED_CLI_OUT
+    assert os.path.exists(exe), "ndzip_amd/ndzip-hip-sharded is missing: python -m ndzip_amd.build"
+    data = synth_numpy(extent, dtype, seed=11, noise_mask=0xFF)
+    want = oracle.compress(data)
+    src, ndz, ref, back = tmp_path / "in.bin", tmp_path / "out.ndz", tmp_path / "ref.ndz", tmp_path / "back.bin"
+    data.tofile(src)
+    want.tofile(ref)
+    t = ["-t", "float" if np.dtype(dtype).itemsize == 4 else "double"]
+    size = [str(x) for x in extent]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "-n", *size, *t, "-i", str(src), "-o", str(ndz), "--repeat", "3", *extra], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and expect in r.stderr, r.stderr[-2000:]
+    got = np.fromfile(ndz, dtype=want.dtype)
+    assert len(got) == len(want) and np.array_equal(got, want), "the ranks' pieces do not add up to the reference stream"
+    r = subprocess.run([exe, "-d", "-n", *size, *t, "-i", str(ref), "-o", str(back), *extra], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.fromfile(back, dtype=want.dtype), data.reshape(-1).view(want.dtype))
+
+
+@pytest.mark.gpu
+@pytest.mark.hardware_only
+@pytest.mark.parametrize("dtype,extent,ranks", [(np.float32, (70, 50, 36), 1), (np.float32, (96, 64, 48), 3), (np.float64, (64 * 5 + 5, 130), 4),
+                                                (np.float64, (4096 * 6 + 5,), 2), (np.float32, (256, 256, 256), 4)])
+def test_file_tool_several_ranks_on_one_gpu(tmp_path, dtype, extent, ranks):
+    """--devices 1: the ranks share GPU 0 (in-process exchange, device work one rank at a time)."""
+    _run_tool(tmp_path, dtype, extent, ["--ranks", str(ranks), "--devices", "1"], f"{ranks} rank(s) on 1 GPU(s), exchange {'none' if ranks == 1 else 'local'}")
+
+
+@pytest.mark.gpu
+@pytest.mark.hardware_only
+@pytest.mark.skipif(_gpus() < 2, reason="needs at least 2 GPUs (one rank per GPU, RCCL)")
+@pytest.mark.parametrize("exchange", ["rccl", "local"])
+def test_file_tool_one_rank_per_gpu(tmp_path, exchange):
+    world = _gpus()
+    _run_tool(tmp_path, np.float32, (16 * (world + 1) + 5, 64, 48), ["--exchange", exchange], f"{world} rank(s) on {world} GPU(s), exchange {exchange}")

@@ -225,6 +225,7 @@ inline hipError_t hipGetDeviceCount(int *n) {
     *n = 1;
     return hipSuccess;
 }
+inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }  // (one "device")
 inline hipError_t hipGetDevice(int *d) {
     *d = 0;
     return hipSuccess;
