@@ -285,7 +285,8 @@ int local_all_gather_u32(void *ctx, const uint32_t *d_send, uint32_t *d_recv, si
     c->group->wait();
     int rc = 0;
     for (uint32_t r = 0; r < c->group->world && rc == 0; ++r) {
-        if (hipMemcpyAsync(d_recv + r * count, c->group->send[r], count * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream) != hipSuccess) rc = 2;
+        // (hipMemcpyDefault: the runtime infers both sides from the unified address space -- rank r's buffer may live on another GPU)
+        if (hipMemcpyAsync(d_recv + r * count, c->group->send[r], count * sizeof(uint32_t), hipMemcpyDefault, stream) != hipSuccess) rc = 2;
     }
     if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess) rc = 3;
     c->group->wait();  // nobody overwrites its send buffer before everybody has read it (reached even on an error: no rank is left waiting)
