@@ -213,3 +213,165 @@ def test_fused_integer_operations_as_llvm_selects_them():
         assert np.array_equal(regs["v0"], want), (name, body)
     for op in ("v_lshl_add_u32", "v_add_lshl_u32", "v_lshl_or_b32", "v_add3_u32", "v_xad_u32", "v_bfe_u32", "v_bfe_i32", "v_alignbit_b32"):
         assert op in seen, f"LLVM no longer selects {op} here: {sorted(seen)}"
+
+
+# ---- whole micro-functions: llc's gfx950 code for integer IR, executed by the interpreter on a real Wave -------------------------------
+
+M64 = (1 << 64) - 1
+
+
+def _u64(x):
+    return np.asarray(x, dtype=np.uint64)
+
+
+WIDE = {  # name: (signature, IR body -> %r, numpy on uint64 x, y [and uint32 a, b]) ; i64 arguments arrive in v[0:1], v[2:3], the result leaves in v[0:1]
+    "add64": ("i64 %x, i64 %y", "i64", "%r = add i64 %x, %y", lambda x, y: x + y),
+    "sub64": ("i64 %x, i64 %y", "i64", "%r = sub i64 %x, %y", lambda x, y: x - y),                       # v_sub_co_u32 / v_subb_co_u32: the f64 stencil's borrow chain
+    "lshl_add64": ("i64 %x, i64 %y", "i64", "%t = shl i64 %x, 3\n  %r = add i64 %t, %y", lambda x, y: (x << np.uint64(3)) + y),
+    "diff_of_sums": ("i64 %x, i64 %y", "i64", "%n = xor i64 %y, -1\n  %t = add i64 %x, %n\n  %r = add i64 %t, 1", lambda x, y: x + (~y) + np.uint64(1)),
+    "rotl1_64": ("i64 %x, i64 %y", "i64", "%h = shl i64 %x, 1\n  %l = lshr i64 %x, 63\n  %r = or i64 %h, %l", lambda x, y: (x << np.uint64(1)) | (x >> np.uint64(63))),
+    "rotr1_64": ("i64 %x, i64 %y", "i64", "%h = lshr i64 %x, 1\n  %l = shl i64 %x, 63\n  %r = or i64 %h, %l", lambda x, y: (x >> np.uint64(1)) | (x << np.uint64(63))),
+    "shl64_var": ("i64 %x, i64 %y", "i64", "%s = and i64 %y, 63\n  %r = shl i64 %x, %s", lambda x, y: x << (y & np.uint64(63))),
+    "lshr64_var": ("i64 %x, i64 %y", "i64", "%s = and i64 %y, 63\n  %r = lshr i64 %x, %s", lambda x, y: x >> (y & np.uint64(63))),
+    "ashr64_63": ("i64 %x, i64 %y", "i64", "%r = ashr i64 %x, 63", lambda x, y: (x.view(np.int64) >> np.int64(63)).view(np.uint64)),
+    "complement_negative64": ("i64 %x, i64 %y", "i64", "%m = ashr i64 %x, 63\n  %k = and i64 %m, 9223372036854775807\n  %r = xor i64 %x, %k",
+                              lambda x, y: x ^ ((x.view(np.int64) >> np.int64(63)).view(np.uint64) & np.uint64(0x7FFFFFFFFFFFFFFF))),
+    "and_or_xor64": ("i64 %x, i64 %y", "i64", "%a = and i64 %x, %y\n  %o = or i64 %x, %y\n  %r = xor i64 %a, %o", lambda x, y: (x & y) ^ (x | y)),
+    "umin64": ("i64 %x, i64 %y", "i64", "%k = icmp ult i64 %x, %y\n  %r = select i1 %k, i64 %x, i64 %y", lambda x, y: np.minimum(x, y)),
+    "smax64": ("i64 %x, i64 %y", "i64", "%k = icmp sgt i64 %x, %y\n  %r = select i1 %k, i64 %x, i64 %y", lambda x, y: np.maximum(x.view(np.int64), y.view(np.int64)).view(np.uint64)),
+    "mul64": ("i64 %x, i64 %y", "i64", "%r = mul i64 %x, %y", lambda x, y: x * y),
+    "mulhi32": ("i64 %x, i64 %y", "i64", "%a = and i64 %x, 4294967295\n  %b = and i64 %y, 4294967295\n  %m = mul i64 %a, %b\n  %r = lshr i64 %m, 32",
+                lambda x, y: ((x & np.uint64(0xFFFFFFFF)) * (y & np.uint64(0xFFFFFFFF))) >> np.uint64(32)),   # the tile origin's magic-number division
+    "mad_u64_u32": ("i64 %x, i64 %y", "i64", "%a = and i64 %x, 4294967295\n  %b = lshr i64 %x, 32\n  %m = mul i64 %a, %b\n  %r = add i64 %m, %y",
+                    lambda x, y: (x & np.uint64(0xFFFFFFFF)) * (x >> np.uint64(32)) + y),
+    "popcount": ("i64 %x, i64 %y", "i64", "%c = call i64 @llvm.ctpop.i64(i64 %x)\n  %r = add i64 %c, %y",
+                 lambda x, y: np.array([bin(int(v)).count("1") for v in x], dtype=np.uint64) + y),                  # the decoders' popcount offsets
+    "eq_select": ("i64 %x, i64 %y", "i64", "%k = icmp eq i64 %x, 0\n  %r = select i1 %k, i64 %y, i64 %x", lambda x, y: np.where(x == 0, y, x)),
+}
+
+
+def _run_llc_function(asm_body, regs64):
+    """Execute the straight-line gfx950 code llc made of one function on a Wave of the interpreter; returns the Wave."""
+    from tests import gfx950_exec as gx
+
+    w = gx.Wave(None, 0, {}, 0, "llc")
+    for k, val in regs64.items():  # {first VGPR of the pair: uint64[64]}
+        w.v[k] = (val & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        w.v[k + 1] = (val >> np.uint64(32)).astype(np.uint32)
+    executed = []
+    for line in asm_body.splitlines():
+        line = line.split(";")[0].strip()
+        if not line or line.endswith(":") or line.startswith("."):
+            continue
+        op, _, rest = line.partition(" ")
+        if op == "s_setpc_b64":
+            break
+        args, mods = gx._split_operands(rest.strip())
+        ins = gx.Ins(op, args, mods, 0, 4, line)
+        if op not in gx.OPS:
+            raise KeyError(op)
+        gx.OPS[op](w, ins)
+        executed.append(op)
+    return w, executed
+
+
+def test_integer_micro_functions_compiled_by_llc_run_right_on_the_interpreter():
+    """Wider than single opcodes: 64-bit adds and borrow chains, shifts by a register, rotates, compares and selects, 32 x 32 -> 64
+    multiplies, multiply-adds and population counts -- each a small IR function compiled by llc for gfx950 and executed, VCC and all, by
+    the interpreter that runs the BUILT kernels in this suite.  The values are checked against plain 64-bit arithmetic."""
+    ir = ['target triple = "amdgcn-amd-amdhsa"', "declare i64 @llvm.ctpop.i64(i64)"]
+    for name, (sig, ret, body, _) in WIDE.items():
+        ir.append(f"define {ret} @{name}({sig}) {{\n  {body}\n  ret {ret} %r\n}}")
+    r = subprocess.run([os.path.join(LLVM, "llc"), "-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-O2", "-o", "-"], input="\n".join(ir), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(6)
+    x = rng.integers(0, 1 << 64, size=64, dtype=np.uint64)
+    y = rng.integers(0, 1 << 64, size=64, dtype=np.uint64)
+    x[:6] = [0, 1, M64, 1 << 63, (1 << 63) - 1, 1 << 32]            # carries, borrows and sign edges
+    y[:6] = [0, M64, 1, 1, 1 << 63, (1 << 32) - 1]
+    seen, skipped = set(), []
+    for name, (_, _, _, fn) in WIDE.items():
+        body = re.search(rf"^{name}:.*?s_setpc_b64[^\n]*", r.stdout, re.S | re.M).group(0)
+        try:
+            w, executed = _run_llc_function(body.split("\n", 1)[1], {0: x, 2: y})
+        except KeyError as e:  # (an opcode the kernels never use and the interpreter therefore does not know: not this test's subject)
+            skipped.append((name, str(e)))
+            continue
+        seen.update(o.replace("_e32", "").replace("_e64", "") for o in executed)
+        got = w.v[0].astype(np.uint64) | (w.v[1].astype(np.uint64) << np.uint64(32))
+        with np.errstate(over="ignore"):
+            want = _u64(fn(x, y))
+        assert np.array_equal(got, want), (name, body)
+    assert len(skipped) <= 3, skipped
+    for op in ("v_lshl_add_u64", "v_sub_co_u32", "v_subb_co_u32", "v_alignbit_b32", "v_lshlrev_b64", "v_lshrrev_b64", "v_mad_u64_u32", "v_cndmask_b32", "v_bcnt_u32_b32"):
+        assert op in seen, f"{op} was not exercised: {sorted(seen)}; skipped {skipped}"
+
+
+M32 = (1 << 32) - 1
+
+
+def _sx(v, bits):
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+SCALAR = {  # uniform arithmetic (the tile origin, running pointers, lengths): (IR body over i32 %a %b, i64 %z %w -> i64 %r, the same on Python ints)
+    "s_mad": ("%x = zext i32 %a to i64\n  %y = zext i32 %b to i64\n  %m = mul i64 %x, %y\n  %r = add i64 %m, %z", lambda a, b, z, w: a * b + z),
+    "s_udiv12": ("%q = udiv i32 %a, 12\n  %r = zext i32 %q to i64", lambda a, b, z, w: a // 12),               # magic-number division
+    "s_udiv_row": ("%q = udiv i32 %a, 510\n  %m = urem i32 %a, 510\n  %t = mul i32 %q, %b\n  %u = add i32 %t, %m\n  %r = zext i32 %u to i64",
+                   lambda a, b, z, w: ((a // 510) * b + a % 510) & M32),
+    "s_add64": ("%r = add i64 %z, %w", lambda a, b, z, w: z + w),
+    "s_sub64": ("%r = sub i64 %z, %w", lambda a, b, z, w: z - w),
+    "s_shl64": ("%s = and i32 %a, 63\n  %e = zext i32 %s to i64\n  %r = shl i64 %z, %e", lambda a, b, z, w: z << (a & 63)),
+    "s_lshr64": ("%s = and i32 %a, 63\n  %e = zext i32 %s to i64\n  %r = lshr i64 %z, %e", lambda a, b, z, w: z >> (a & 63)),
+    "s_andn2": ("%n = xor i64 %w, -1\n  %r = and i64 %z, %n", lambda a, b, z, w: z & ~w),
+    "s_orn2": ("%n = xor i64 %w, -1\n  %r = or i64 %z, %n", lambda a, b, z, w: z | (~w & M64)),
+    "s_umin": ("%k = icmp ult i32 %a, %b\n  %m = select i1 %k, i32 %a, i32 %b\n  %r = zext i32 %m to i64", lambda a, b, z, w: min(a, b)),
+    "s_smax": ("%k = icmp sgt i32 %a, %b\n  %m = select i1 %k, i32 %a, i32 %b\n  %r = zext i32 %m to i64", lambda a, b, z, w: max(_sx(a, 32), _sx(b, 32)) & M32),
+    "s_cselect": ("%k = icmp uge i32 %a, %b\n  %r = select i1 %k, i64 %z, i64 %w", lambda a, b, z, w: z if a >= b else w),
+    "s_lshl_add": ("%t = shl i32 %a, 2\n  %u = add i32 %t, %b\n  %r = zext i32 %u to i64", lambda a, b, z, w: ((a << 2) + b) & M32),
+    "s_bfe": ("%t = lshr i32 %a, 5\n  %u = and i32 %t, 1023\n  %r = zext i32 %u to i64", lambda a, b, z, w: (a >> 5) & 1023),
+    "s_mulhi": ("%x = zext i32 %a to i64\n  %y = zext i32 %b to i64\n  %m = mul i64 %x, %y\n  %r = lshr i64 %m, 32", lambda a, b, z, w: (a * b) >> 32),
+    "s_ashr": ("%x = ashr i64 %z, 63\n  %r = xor i64 %x, %w", lambda a, b, z, w: ((M64 if z >> 63 else 0) ^ w)),
+}
+
+
+def test_uniform_integer_functions_compiled_by_llc_run_right_on_the_interpreter():
+    """The scalar side the same way: llc's SALU code for gfx950 (s_mul_i32 / s_mul_hi_u32 magic divisions, s_add_u32 / s_addc_u32 and
+    s_sub_u32 / s_subb_u32 through SCC, 64-bit shifts, s_andn2 / s_orn2, s_min / s_max, s_cmp + s_cselect, s_lshlN_add_u32, s_bfe)
+    on the interpreter's scalar state.  (Shader calling convention: inreg arguments arrive in s2.., the result leaves in s[0:1].)"""
+    from tests import gfx950_exec as gx
+
+    ir = ['target triple = "amdgcn--mesa3d"']
+    for name, (body, _) in SCALAR.items():
+        ir.append(f"define amdgpu_cs inreg i64 @{name}(i32 inreg %a, i32 inreg %b, i64 inreg %z, i64 inreg %w) {{\n  {body}\n  ret i64 %r\n}}")
+    r = subprocess.run([os.path.join(LLVM, "llc"), "-mtriple=amdgcn--mesa3d", "-mcpu=gfx950", "-O2", "-o", "-"], input="\n".join(ir), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(7)
+    tuples = [(0, 0, 0, 0), (M32, M32, M64, M64), (1, M32, M64, 1), (1 << 31, 1, 1 << 63, (1 << 63) - 1), (509, 510, 1 << 32, M32), (510, 4096, M32, 1 << 32)]
+    tuples += [(int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 64, dtype=np.uint64)), int(rng.integers(0, 1 << 64, dtype=np.uint64)))
+               for _ in range(34)]
+    seen, skipped = set(), []
+    names = list(SCALAR)
+    for k, name in enumerate(names):
+        nxt = names[k + 1] if k + 1 < len(names) else None
+        m = re.search(rf"^{name}:(.*?)(?=^{nxt}:)" if nxt else rf"^{name}:(.*)", r.stdout, re.S | re.M)
+        body = [l.split(";")[0].strip() for l in m.group(1).splitlines()]
+        body = [l for l in body if l and not l.endswith(":") and not l.startswith(".") and l.split()[0].startswith(("s_", "v_"))]
+        if any(l.split()[0] not in gx.OPS for l in body):
+            skipped.append((name, [l.split()[0] for l in body if l.split()[0] not in gx.OPS]))
+            continue
+        for a, b, z, wv in tuples:
+            w = gx.Wave(None, 0, {}, 0, "llc")
+            w.s[2], w.s[3], w.s[4], w.s[5], w.s[6], w.s[7] = a, b, z & M32, z >> 32, wv & M32, wv >> 32
+            for line in body:
+                op, _, rest = line.partition(" ")
+                if op in ("s_endpgm", "s_setpc_b64"):
+                    break
+                args, mods = gx._split_operands(rest.strip())
+                gx.OPS[op](w, gx.Ins(op, args, mods, 0, 4, line))
+                seen.add(op)
+            got = (w.s[0] & M32) | ((w.s[1] & M32) << 32)
+            assert got == SCALAR[name][1](a, b, z, wv) & M64, (name, hex(a), hex(b), hex(z), hex(wv), body)
+    assert len(skipped) <= 3, skipped
+    for op in ("s_mul_i32", "s_mul_hi_u32", "s_add_u32", "s_addc_u32", "s_sub_u32", "s_subb_u32", "s_lshl_b64", "s_lshr_b64", "s_andn2_b64", "s_orn2_b64", "s_cselect_b32", "s_bfe_u32", "s_min_u32", "s_max_i32"):
+        assert op in seen, f"{op} was not exercised: {sorted(seen)}; skipped {skipped}"
