@@ -230,3 +230,214 @@ def test_the_wave_scan_llvm_builds_for_a_divergent_atomic(objects, strategy):
     want = np.where(active, np.uint32(1000) + prefix, np.uint32(0xFFFFFFFF))
     assert np.array_equal(out, want), np.flatnonzero(out != want)[:8]
     assert int(total[0]) == 1000 + int(v[active].sum())
+
+
+# ---- the five hand-written assembly blocks: assembled form == hipcc's compilation of the C++ fallback == the definition --------------
+#
+# ndzip_amd/csrc/gfx950_lds.hpp holds each block twice: as gfx950 assembly and, behind -DNDZIP_NO_EXEC_ASM, as plain C++ /
+# __builtin_amdgcn_update_dpp that means the same.  Both forms are compiled into kernels that do nothing else, executed by the
+# interpreter on the same random data, and held against what the operation IS (a 64-bit prefix sum, a pair exchange, a compaction) in
+# numpy.  The interpreter's reading of the opcodes the FALLBACK compiles to is what the tests above and
+# tests/test_isa_primitives_crosscheck.py pin to LLVM; the assembly has to land on the same numbers.
+
+ASM_SOURCE = r"""
+#include "gfx950_lds.hpp"
+using namespace ndzip_hip;
+template<int D> __device__ void row_kernel(const uint32_t *in, uint32_t *out) {
+    uint32_t lo[8], hi[8];
+    for (int j = 0; j < 8; ++j) { lo[j] = in[threadIdx.x * 16 + j]; hi[j] = in[threadIdx.x * 16 + 8 + j]; }
+    row_scan_step64<D>(lo, hi);
+    for (int j = 0; j < 8; ++j) { out[threadIdx.x * 16 + j] = lo[j]; out[threadIdx.x * 16 + 8 + j] = hi[j]; }
+}
+extern "C" __global__ void k_row1(const uint32_t *in, uint32_t *out) { row_kernel<1>(in, out); }
+extern "C" __global__ void k_row2(const uint32_t *in, uint32_t *out) { row_kernel<2>(in, out); }
+extern "C" __global__ void k_row4(const uint32_t *in, uint32_t *out) { row_kernel<4>(in, out); }
+extern "C" __global__ void k_row8(const uint32_t *in, uint32_t *out) { row_kernel<8>(in, out); }
+extern "C" __global__ void k_scan64(const uint32_t *in, uint32_t *out) {
+    uint32_t lo = in[threadIdx.x * 2], hi = in[threadIdx.x * 2 + 1];
+    wave_inclusive_scan64(lo, hi);
+    out[threadIdx.x * 2] = lo; out[threadIdx.x * 2 + 1] = hi;
+}
+extern "C" __global__ void k_pair(const uint32_t *in, uint32_t *out) {
+    uint32_t a[4], b[4], lo[4], hi[4];
+    for (int j = 0; j < 4; ++j) { a[j] = in[threadIdx.x * 8 + j]; b[j] = in[threadIdx.x * 8 + 4 + j]; }
+    pair_exchange_select4(threadIdx.x & 1u, a, b, lo, hi);
+    for (int j = 0; j < 4; ++j) { out[threadIdx.x * 8 + j] = lo[j]; out[threadIdx.x * 8 + 4 + j] = hi[j]; }
+}
+// every lane compacts its 32 words into its own 128-byte region of LDS (zeroed first); lanes with skip[t] sit the compaction out, so
+// the block is entered under a PARTIAL exec mask; then every lane copies its region and the end address it got back out
+extern "C" __global__ void k_append(const uint32_t *in, uint32_t *out, uint32_t *ends, const uint32_t *skip) {
+    __shared__ uint32_t lds[64 * 32];
+    const int t = threadIdx.x;
+    uint32_t w[32];
+    for (int j = 0; j < 32; ++j) { w[j] = in[t * 32 + j]; lds[t * 32 + j] = 0; }
+    __syncthreads();
+    uint32_t end = 0xffffffffu;
+    if (!skip[t]) end = lds_append_nonzero(lds_address(lds) + t * 128, w) - (lds_address(lds) + t * 128);
+    lds_append_complete();
+    __syncthreads();
+    for (int j = 0; j < 32; ++j) out[t * 32 + j] = lds[t * 32 + j];
+    ends[t] = end;
+}
+// the 64-bit profiles' compaction: dword w[i] kept where bit 31 - i of flags is set, stored at the XOR-swizzled address, the running
+// address advancing by 8; a lane's region is 256 bytes (the swizzle stays inside a 128-byte block)
+extern "C" __global__ void k_append64(const uint32_t *in, const uint32_t *flags, uint32_t *out, const uint32_t *skip) {
+    __shared__ uint32_t lds[64 * 64];
+    const int t = threadIdx.x;
+    uint32_t w[32];
+    for (int j = 0; j < 32; ++j) w[j] = in[t * 32 + j];
+    for (int j = 0; j < 64; ++j) lds[t * 64 + j] = 0;
+    __syncthreads();
+    if (!skip[t]) lds_append_flagged64(lds_address(lds) + t * 256, flags[t], w);
+    lds_append_complete();
+    __syncthreads();
+    for (int j = 0; j < 64; ++j) out[t * 64 + j] = lds[t * 64 + j];
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def asm_objects(tmp_path_factory):
+    from tests import gfx950_exec as gx
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path_factory.mktemp("asmblocks")
+    (d / "b.hip").write_text(ASM_SOURCE)
+    out = {}
+    for name, flags in (("assembled", []), ("compiled", ["-DNDZIP_NO_EXEC_ASM"])):
+        co = d / f"{name}.hsaco"
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "--no-gpu-bundle-output", "-I", os.path.join(root, "ndzip_amd", "csrc"), *flags,
+                            str(d / "b.hip"), "-o", str(co)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = gx.CodeObject(str(co))
+    return out
+
+
+def _both(asm_objects, kernel, make_args):
+    """run `kernel` from both code objects on identical inputs; returns {form: output arrays}"""
+    res = {}
+    for form, co in asm_objects.items():
+        args, outs = make_args()
+        ops = _run(co, kernel, 1, 64, *args)
+        res[form] = (outs, ops)
+    return res
+
+
+def _pairs64(words, n):
+    """[64 lanes][n] uint64 from the kernels' layout: per lane n low dwords, then n high dwords"""
+    w = words.reshape(64, 2 * n).astype(np.uint64)
+    return w[:, :n] | (w[:, n:] << np.uint64(32))
+
+
+@pytest.mark.parametrize("D", [1, 2, 4, 8])
+def test_row_scan_step64_both_forms_are_the_row_shifted_sum(asm_objects, D):
+    rng = np.random.default_rng(10 + D)
+    data = rng.integers(0, 1 << 32, size=64 * 16, dtype=np.uint64).astype(np.uint32)
+    data[:16] = 0xFFFFFFFF  # (carries out of the low dword)
+
+    def make():
+        out = np.zeros(64 * 16, dtype=np.uint32)
+        return (data, out), out
+
+    res = _both(asm_objects, f"k_row{D}", make)
+    assert "v_add_co_u32_dpp" in res["assembled"][1] and "v_add_co_u32_dpp" not in res["compiled"][1]
+    x = _pairs64(data, 8)
+    lane = np.arange(64)
+    shifted = np.where(((lane % 16) >= D)[:, None], x[np.maximum(lane - D, 0)], np.uint64(0))   # row_shr:D, zeros shifted in (bound_ctrl)
+    want = x + shifted
+    for form in res:
+        assert np.array_equal(_pairs64(res[form][0], 8), want), form
+
+
+def test_wave_inclusive_scan64_both_forms_are_the_prefix_sum(asm_objects):
+    rng = np.random.default_rng(20)
+    data = rng.integers(0, 1 << 32, size=128, dtype=np.uint64).astype(np.uint32)
+    data[0:40:2] = 0xFFFFFFFF
+
+    def make():
+        out = np.zeros(128, dtype=np.uint32)
+        return (data, out), out
+
+    res = _both(asm_objects, "k_scan64", make)
+    x = data[0::2].astype(np.uint64) | (data[1::2].astype(np.uint64) << np.uint64(32))
+    want = np.cumsum(x, dtype=np.uint64)
+    for form in res:
+        got = res[form][0][0::2].astype(np.uint64) | (res[form][0][1::2].astype(np.uint64) << np.uint64(32))
+        assert np.array_equal(got, want), form
+
+
+def test_pair_exchange_select4_both_forms(asm_objects):
+    rng = np.random.default_rng(30)
+    data = rng.integers(0, 1 << 32, size=64 * 8, dtype=np.uint64).astype(np.uint32)
+
+    def make():
+        out = np.zeros(64 * 8, dtype=np.uint32)
+        return (data, out), out
+
+    res = _both(asm_objects, "k_pair", make)
+    assert "v_cndmask_b32_dpp" in res["assembled"][1]
+    v = data.reshape(64, 8)
+    a, b = v[:, :4], v[:, 4:]
+    lane = np.arange(64)
+    odd = (lane & 1).astype(bool)[:, None]
+    other = lane ^ 1
+    want = np.concatenate([np.where(odd, b, a[other]), np.where(odd, b[other], a)], axis=1)  # lo = odd ? own b : the other lane's a; hi = odd ? the other lane's b : own a
+    for form in res:
+        assert np.array_equal(res[form][0].reshape(64, 8), want), form
+
+
+def test_lds_append_nonzero_both_forms_under_a_partial_exec_mask(asm_objects):
+    rng = np.random.default_rng(40)
+    data = rng.integers(0, 1 << 32, size=64 * 32, dtype=np.uint64).astype(np.uint32)
+    data[rng.random(64 * 32) < 0.45] = 0
+    data[3 * 32:4 * 32] = 0          # a lane that keeps nothing
+    data[4 * 32:5 * 32] |= 1         # ... and one that keeps everything
+
+    skip = (np.arange(64) % 5 == 2).astype(np.uint32)
+
+    def make():
+        out, ends = np.zeros(64 * 32, dtype=np.uint32), np.zeros(64, dtype=np.uint32)
+        return (data, out, ends, skip), (out, ends)
+
+    res = _both(asm_objects, "k_append", make)
+    assert "v_cmpx_ne_u32_e32" in res["assembled"][1] and "v_cmpx_ne_u32_e32" not in res["compiled"][1]
+    want, ends = np.zeros((64, 32), dtype=np.uint32), np.zeros(64, dtype=np.uint32)
+    for t in range(64):
+        if t % 5 == 2:
+            ends[t] = 0xFFFFFFFF
+            continue
+        kept = data[t * 32:(t + 1) * 32]
+        kept = kept[kept != 0]
+        want[t, :len(kept)] = kept
+        ends[t] = 4 * len(kept)
+    for form in res:
+        out, got_ends = res[form][0]
+        assert np.array_equal(out.reshape(64, 32), want) and np.array_equal(got_ends, ends), form
+
+
+def test_lds_append_flagged64_both_forms_under_a_partial_exec_mask(asm_objects):
+    rng = np.random.default_rng(50)
+    data = rng.integers(0, 1 << 32, size=64 * 32, dtype=np.uint64).astype(np.uint32)
+    flags = rng.integers(0, 1 << 32, size=64, dtype=np.uint64).astype(np.uint32)
+    flags[:4] = [0, 0xFFFFFFFF, 0x80000000, 1]
+
+    skip = (np.arange(64) % 7 == 3).astype(np.uint32)
+
+    def make():
+        out = np.zeros(64 * 64, dtype=np.uint32)
+        return (data, flags, out, skip), out
+
+    res = _both(asm_objects, "k_append64", make)
+    assert "v_cmpx_gt_i32_e32" in res["assembled"][1] and "v_bitop3_b32" in res["assembled"][1]
+    want = np.zeros((64, 64), dtype=np.uint32)
+    for t in range(64):
+        if t % 7 == 3:
+            continue
+        a = t * 256   # (the swizzle depends on the address within the workgroup's LDS: lds[] starts at 0 in these kernels)
+        for i in range(32):
+            if (int(flags[t]) >> (31 - i)) & 1:
+                at = a ^ ((a >> 3) & 0x70)
+                want[at // 256, (at % 256) // 4] = data[t * 32 + i]
+                a += 8
+    for form in res:
+        assert np.array_equal(res[form][0].reshape(64, 64), want), form
