@@ -441,3 +441,87 @@ def test_lds_append_flagged64_both_forms_under_a_partial_exec_mask(asm_objects):
                 a += 8
     for form in res:
         assert np.array_equal(res[form][0].reshape(64, 64), want), form
+
+
+# ---- the two emulators against each other on DPP: every control the kernels use (and their neighbours), full and partial EXEC ---------
+#
+# The same source twice: hipcc -> gfx950 code object -> the interpreter; host compiler + tests/wavesim (the functional model the
+# kernels' C++ runs on in most of this suite).  The interpreter's DPP reading is anchored above (LLVM's own wave scan, the compiled
+# fallbacks of the asm blocks); the model's must give the same lanes, including what happens to `old` under row / bank masks, bound_ctrl
+# and inactive source lanes.
+
+DPP_COMBOS = [(ctrl, rm, bm, bc) for ctrl in (0xB1, 0x4E, 0x1B, 0x111, 0x112, 0x114, 0x118, 0x101, 0x104, 0x121, 0x128, 0x138, 0x130, 0x140, 0x141, 0x142, 0x143)
+              for rm, bm, bc in ((0xF, 0xF, 1), (0xF, 0xF, 0), (0xA, 0xF, 0), (0xC, 0xF, 0), (0xF, 0xA, 0), (0x5, 0x6, 1))]
+
+DPP_SOURCE = "#include <hip/hip_runtime.h>\n#include <cstdint>\n" + r"""
+template<int Ctrl, int RowMask, int BankMask, bool Bound>
+__device__ uint32_t one(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v ^ 0x5a5a5a5au), static_cast<int>(v), Ctrl, RowMask, BankMask, Bound));
+}
+__global__ void k_dpp(const uint32_t *in, const uint32_t *skip, uint32_t *out) {
+    const int t = threadIdx.x;
+    const uint32_t v = in[t];
+    uint32_t *full = out + t * COUNT * 2, *part = full + COUNT;
+    int c = 0;
+#define STEP(ctrl, rm, bm, bc) full[c++] = one<ctrl, rm, bm, bc>(v);
+    COMBOS
+#undef STEP
+    for (int k = 0; k < COUNT; ++k) part[k] = 0xeeeeeeeeu;
+    if (!skip[t]) {
+        c = 0;
+#define STEP(ctrl, rm, bm, bc) part[c++] = one<ctrl, rm, bm, bc>(v);
+        COMBOS
+#undef STEP
+    }
+}
+""".replace("COMBOS", " ".join(f"STEP({c}, {rm}, {bm}, {'true' if bc else 'false'})" for c, rm, bm, bc in DPP_COMBOS)).replace("COUNT", str(len(DPP_COMBOS)))
+
+DPP_HOST_MAIN = r"""
+#include <cstdio>
+#include <vector>
+int main(int argc, char **argv) {
+    std::vector<uint32_t> in(64), skip(64), out(64 * COUNT * 2);
+    FILE *f = fopen(argv[1], "rb");
+    if (!f || fread(in.data(), 4, 64, f) != 64 || fread(skip.data(), 4, 64, f) != 64) return 2;
+    fclose(f);
+    hipLaunchKernelGGL(k_dpp, dim3(1), dim3(64), 0, nullptr, in.data(), skip.data(), out.data());
+    f = fopen(argv[2], "wb");
+    if (!f || fwrite(out.data(), 4, out.size(), f) != out.size()) return 3;
+    fclose(f);
+    return 0;
+}
+""".replace("COUNT", str(len(DPP_COMBOS)))
+
+
+def test_the_functional_model_and_the_interpreter_agree_on_dpp(tmp_path):
+    from tests import gfx950_exec as gx
+    from tests.wavesim import build as simbuild
+
+    here = os.path.dirname(os.path.abspath(simbuild.__file__))
+    rng = np.random.default_rng(60)
+    v = rng.integers(0, 1 << 32, size=64, dtype=np.uint64).astype(np.uint32)
+    skip = (rng.random(64) < 0.35).astype(np.uint32)
+    skip[[15, 16, 31, 32]] = [1, 0, 1, 1]        # row edges: the lanes a row_shr / row_bcast reads are inactive
+    n = len(DPP_COMBOS)
+    # the interpreter on hipcc's code
+    (tmp_path / "d.hip").write_text(DPP_SOURCE.replace("__global__", 'extern "C" __global__'))
+    co = tmp_path / "d.hsaco"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "--no-gpu-bundle-output", str(tmp_path / "d.hip"), "-o", str(co)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out_i = np.zeros(64 * n * 2, dtype=np.uint32)
+    ops = _run(gx.CodeObject(str(co)), "k_dpp", 1, 64, v, skip, out_i)
+    assert any(o.endswith("_dpp") for o in ops)
+    # the model on the host compiler's code
+    (tmp_path / "d.cc").write_text(DPP_SOURCE + DPP_HOST_MAIN)
+    exe = tmp_path / "dpp_model"
+    r = subprocess.run([simbuild.CXX, "-std=c++17", "-O1", "-pthread", "-Wno-unknown-attributes", "-I", here, str(tmp_path / "d.cc"), os.path.join(here, "wavesim.cc"), "-ldl",
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    np.concatenate([v, skip]).tofile(tmp_path / "in.bin")
+    r = subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    out_m = np.fromfile(tmp_path / "out.bin", dtype=np.uint32)
+    a, b = out_i.reshape(64, 2, n), out_m.reshape(64, 2, n)
+    bad = np.argwhere(a != b)
+    assert bad.size == 0, [(int(t), "partial" if h else "full", tuple(hex(x) for x in DPP_COMBOS[c]), hex(int(a[t, h, c])), hex(int(b[t, h, c]))) for t, h, c in bad[:6]]
+    assert (a[skip.astype(bool), 1] == 0xEEEEEEEE).all()   # lanes that sat the partial pass out wrote nothing

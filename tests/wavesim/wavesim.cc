@@ -87,6 +87,7 @@ struct claim_value {
 
 struct wave_state {
     uint64_t slot[2][64];
+    uint64_t present[2] = {0, 0};  // lanes that deposited into slot[k] in its current rendezvous: the ACTIVE lanes of that wave operation
     unsigned arrived = 0;
     unsigned gen = 0;  // completed rendezvous
     unsigned alive = 64;
@@ -357,8 +358,9 @@ void barrier() {
 }
 
 namespace {
-// deposit v, wait for the wavefront, return the buffer the values of this rendezvous sit in
-const uint64_t *rendezvous(uint64_t v, unsigned tag, void *site) {
+// deposit v, wait for the wavefront, return the buffer the values of this rendezvous sit in (*active: the lanes that took part --
+// lanes that have left the kernel, the only way a lane can be inactive in a wave operation here, hold stale values in the buffer)
+const uint64_t *rendezvous(uint64_t v, unsigned tag, void *site, uint64_t *active = nullptr) {
     lane_ctx *l = g_self;
     wg_state *wg = l->wg;
     wave_state &w = wg->waves[l->tid / 64];
@@ -366,10 +368,12 @@ const uint64_t *rendezvous(uint64_t v, unsigned tag, void *site) {
     uint64_t *buf = w.slot[gen & 1u];
     if (w.arrived == 0) {
         w.tag = tag;
+        w.present[gen & 1u] = 0;
     } else if (w.tag != tag) {
         die("lanes of one wavefront meet in different wave operations (divergent control flow around a shuffle / ballot / DPP)");
     }
     buf[l->tid & 63u] = v;
+    w.present[gen & 1u] |= uint64_t{1} << (l->tid & 63u);
     if (++w.arrived == w.alive) {
         w.arrived = 0;
         w.tag = op_none;
@@ -382,6 +386,7 @@ const uint64_t *rendezvous(uint64_t v, unsigned tag, void *site) {
         l->site = site;
         yield_to_scheduler();
     }
+    if (active) *active = w.present[gen & 1u];  // (complete: every lane that is still alive has deposited by now)
     return buf;
 }
 }  // namespace
@@ -393,17 +398,17 @@ uint64_t wave_exchange(uint64_t v, int src) {
 }
 
 uint64_t wave_ballot(bool pred) {
-    const uint64_t *buf = rendezvous(pred ? 1u : 0u, op_ballot, __builtin_return_address(0));
-    const wave_state &w = g_self->wg->waves[g_self->tid / 64];
-    (void) w;
+    uint64_t active = 0;
+    const uint64_t *buf = rendezvous(pred ? 1u : 0u, op_ballot, __builtin_return_address(0), &active);
     uint64_t mask = 0;
     for (unsigned i = 0; i < 64; ++i) mask |= (buf[i] & 1u) << i;
-    return mask;
+    return mask & active;  // a ballot counts active lanes only (an inactive lane's bit is 0, whatever it voted last time)
 }
 
 uint32_t update_dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask, unsigned bank_mask, bool bound_ctrl) {
     const int lane = static_cast<int>(g_self->tid & 63u);
-    const uint64_t *buf = rendezvous(src, op_dpp, __builtin_return_address(0));
+    uint64_t active = 0;
+    const uint64_t *buf = rendezvous(src, op_dpp, __builtin_return_address(0), &active);
     const int row = lane >> 4, in_row = lane & 15;
     const bool enabled = ((row_mask >> row) & 1u) && ((bank_mask >> (in_row >> 2)) & 1u);
     if (!enabled) return old;
@@ -437,7 +442,9 @@ uint32_t update_dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask
     } else {
         die("unknown DPP control");
     }
-    if (from < 0) return bound_ctrl ? 0u : old;
+    // gfx9 DPP has no fetch-inactive bit: a source lane that is not active is as invalid as one out of range (round 6: found by holding
+    // the model against the interpreter, whose DPP reading LLVM's own wave scan anchors -- tests/test_interpreter_vs_compiler.py)
+    if (from < 0 || !((active >> from) & 1u)) return bound_ctrl ? 0u : old;
     return static_cast<uint32_t>(buf[from]);
 }
 
