@@ -525,3 +525,90 @@ def test_the_functional_model_and_the_interpreter_agree_on_dpp(tmp_path):
     bad = np.argwhere(a != b)
     assert bad.size == 0, [(int(t), "partial" if h else "full", tuple(hex(x) for x in DPP_COMBOS[c]), hex(int(a[t, h, c])), hex(int(b[t, h, c]))) for t, h, c in bad[:6]]
     assert (a[skip.astype(bool), 1] == 0xEEEEEEEE).all()   # lanes that sat the partial pass out wrote nothing
+
+
+LANES_SOURCE = "#include <hip/hip_runtime.h>\n#include <cstdint>\n" + r"""
+__global__ void k_lanes2(const uint32_t *in, const uint32_t *skip, uint32_t *out) {
+    const int t = threadIdx.x;
+    const uint32_t v = in[t];
+    uint32_t *o = out + t * 12;
+    o[0] = __shfl_xor(v, 1);
+    o[1] = __shfl_xor(v, 8);
+    o[2] = __shfl_xor(v, 32);
+    o[3] = __shfl_up(v, 1u);
+    o[4] = __shfl_up(v, 9u);
+    o[5] = __shfl(v, 13);
+    o[6] = __shfl(v, (t * 11 + 5) & 63);
+    o[7] = __shfl_up(v, 3u, 16);
+    const unsigned long long m = __ballot((v >> 2) & 1);
+    o[8] = (uint32_t) m;
+    o[9] = (uint32_t) (m >> 32);
+    o[10] = 0xeeeeeeeeu;
+    o[11] = 0xeeeeeeeeu;
+    if (!skip[t]) {   // a ballot among the lanes that are left: the others' bits are 0 whatever they voted above
+        const unsigned long long p = __ballot(v & 1);
+        o[10] = (uint32_t) p;
+        o[11] = (uint32_t) (p >> 32);
+    }
+}
+"""
+
+LANES_HOST_MAIN = r"""
+#include <cstdio>
+#include <vector>
+int main(int argc, char **argv) {
+    std::vector<uint32_t> in(64), skip(64), out(64 * 12);
+    FILE *f = fopen(argv[1], "rb");
+    if (!f || fread(in.data(), 4, 64, f) != 64 || fread(skip.data(), 4, 64, f) != 64) return 2;
+    fclose(f);
+    hipLaunchKernelGGL(k_lanes2, dim3(1), dim3(64), 0, nullptr, in.data(), skip.data(), out.data());
+    f = fopen(argv[2], "wb");
+    if (!f || fwrite(out.data(), 4, out.size(), f) != out.size()) return 3;
+    fclose(f);
+    return 0;
+}
+"""
+
+
+def test_shuffles_and_ballots_model_interpreter_and_the_definition(tmp_path):
+    """The functional model's __shfl / __shfl_up / __shfl_xor / __ballot (tests/wavesim/hip/hip_runtime.h) and the interpreter's execution
+    of hipcc's lowering of the same source, both against what HIP defines -- including a ballot under a partial EXEC mask."""
+    from tests import gfx950_exec as gx
+    from tests.wavesim import build as simbuild
+
+    here = os.path.dirname(os.path.abspath(simbuild.__file__))
+    rng = np.random.default_rng(70)
+    v = rng.integers(0, 1 << 32, size=64, dtype=np.uint64).astype(np.uint32)
+    skip = (rng.random(64) < 0.4).astype(np.uint32)
+    lane = np.arange(64)
+    want = np.zeros((64, 12), dtype=np.uint32)
+    want[:, 0], want[:, 1], want[:, 2] = v[lane ^ 1], v[lane ^ 8], v[lane ^ 32]
+    want[:, 3] = v[np.where(lane >= 1, lane - 1, lane)]
+    want[:, 4] = v[np.where(lane >= 9, lane - 9, lane)]
+    want[:, 5] = v[13]
+    want[:, 6] = v[(lane * 11 + 5) & 63]
+    want[:, 7] = v[np.where((lane & 15) >= 3, lane - 3, lane)]
+    m = sum(int((v[k] >> 2) & 1) << k for k in range(64))
+    want[:, 8], want[:, 9] = m & 0xFFFFFFFF, m >> 32
+    p = sum(int(v[k] & 1) << k for k in range(64) if not skip[k])
+    want[:, 10] = np.where(skip, 0xEEEEEEEE, p & 0xFFFFFFFF)
+    want[:, 11] = np.where(skip, 0xEEEEEEEE, p >> 32)
+    # the interpreter
+    (tmp_path / "l.hip").write_text(LANES_SOURCE.replace("__global__", 'extern "C" __global__'))
+    co = tmp_path / "l.hsaco"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "--no-gpu-bundle-output", str(tmp_path / "l.hip"), "-o", str(co)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out_i = np.zeros(64 * 12, dtype=np.uint32)
+    _run(gx.CodeObject(str(co)), "k_lanes2", 1, 64, v, skip, out_i)
+    assert np.array_equal(out_i.reshape(64, 12), want), np.argwhere(out_i.reshape(64, 12) != want)[:6]
+    # the model
+    (tmp_path / "l.cc").write_text(LANES_SOURCE + LANES_HOST_MAIN)
+    exe = tmp_path / "lanes_model"
+    r = subprocess.run([simbuild.CXX, "-std=c++17", "-O1", "-pthread", "-Wno-unknown-attributes", "-I", here, str(tmp_path / "l.cc"), os.path.join(here, "wavesim.cc"), "-ldl",
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    np.concatenate([v, skip]).tofile(tmp_path / "in.bin")
+    r = subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    out_m = np.fromfile(tmp_path / "out.bin", dtype=np.uint32).reshape(64, 12)
+    assert np.array_equal(out_m, want), np.argwhere(out_m != want)[:6]

@@ -105,21 +105,23 @@ inline T wavesim_shfl_src(T v, int src) {
     return out;
 }
 inline int wavesim_lane() { return static_cast<int>(wavesim::lane_thread_idx() & 63u); }
+// (the index arithmetic of HIP's own definitions, amd_warp_functions.h: a value never crosses a `width`-lane segment)
 template<typename T>
 inline T __shfl(T v, int src, int width = 64) {
-    (void) width;
-    return wavesim_shfl_src(v, src & 63);
+    const int self = wavesim_lane();
+    return wavesim_shfl_src(v, (src & (width - 1)) + (self & ~(width - 1)));
 }
 template<typename T>
 inline T __shfl_up(T v, unsigned d, int width = 64) {
-    (void) width;
-    const int l = wavesim_lane();
-    return wavesim_shfl_src(v, l >= static_cast<int>(d) ? l - static_cast<int>(d) : l);
+    const int self = wavesim_lane();
+    const int index = self - static_cast<int>(d);
+    return wavesim_shfl_src(v, index < (self & ~(width - 1)) ? self : index);
 }
 template<typename T>
 inline T __shfl_xor(T v, int mask, int width = 64) {
-    (void) width;
-    return wavesim_shfl_src(v, (wavesim_lane() ^ mask) & 63);
+    const int self = wavesim_lane();
+    const int index = self ^ mask;
+    return wavesim_shfl_src(v, index >= ((self + width) & ~(width - 1)) ? self : index);
 }
 inline unsigned long long __ballot(bool pred) { return wavesim::wave_ballot(pred); }
 
