@@ -107,13 +107,13 @@ def objects(tmp_path_factory):
     return out
 
 
-def _run(co, kernel, grid, block, *args):
+def _run(co, kernel, grid, block, *args, lds=0):
     from tests import gfx950_exec as gx
 
     k = gx.Kernel(co, kernel)
     assert not k.missing, f"{kernel}: the compiler used {k.missing}, which the interpreter does not know (change the SOURCE, not the interpreter)"
     packed = b"".join(struct.pack("<Q", a.ctypes.data) if isinstance(a, np.ndarray) else struct.pack("<i", a) for a in args)
-    gx.run_grid(k, grid, block, 0, packed, resident=4, quantum=500)
+    gx.run_grid(k, grid, block, lds, packed, resident=4, quantum=500)
     return {x.op for x in k.code.values()}
 
 
@@ -235,14 +235,15 @@ def test_the_wave_scan_llvm_builds_for_a_divergent_atomic(objects, strategy):
 # ---- the five hand-written assembly blocks: assembled form == hipcc's compilation of the C++ fallback == the definition --------------
 #
 # ndzip_amd/csrc/gfx950_lds.hpp holds each block twice: as gfx950 assembly and, behind -DNDZIP_NO_EXEC_ASM, as plain C++ /
-# __builtin_amdgcn_update_dpp that means the same.  Both forms are compiled into kernels that do nothing else, executed by the
-# interpreter on the same random data, and held against what the operation IS (a 64-bit prefix sum, a pair exchange, a compaction) in
-# numpy.  The interpreter's reading of the opcodes the FALLBACK compiles to is what the tests above and
+# __builtin_amdgcn_update_dpp that means the same; tests/wavesim/gfx950_lds.hpp holds a THIRD version, the one the functional model runs
+# (assembly has no host meaning).  All three are compiled into kernels that do nothing else -- the first two by hipcc and executed by the
+# interpreter, the third by the host compiler on the model -- run on the same random data, and held against what the operation IS (a
+# 64-bit prefix sum, a pair exchange, a compaction) in numpy.  The interpreter's reading of the opcodes the FALLBACK compiles to is what the tests above and
 # tests/test_isa_primitives_crosscheck.py pin to LLVM; the assembly has to land on the same numbers.
 
 ASM_SOURCE = r"""
 #include "gfx950_lds.hpp"
-using namespace ndzip_hip;
+namespace ndzip_hip {   // (like the product's kernels: `extern __shared__ char smem[]` is the workgroup's dynamic LDS, on the GPU and on the model)
 template<int D> __device__ void row_kernel(const uint32_t *in, uint32_t *out) {
     uint32_t lo[8], hi[8];
     for (int j = 0; j < 8; ++j) { lo[j] = in[threadIdx.x * 16 + j]; hi[j] = in[threadIdx.x * 16 + 8 + j]; }
@@ -267,7 +268,8 @@ extern "C" __global__ void k_pair(const uint32_t *in, uint32_t *out) {
 // every lane compacts its 32 words into its own 128-byte region of LDS (zeroed first); lanes with skip[t] sit the compaction out, so
 // the block is entered under a PARTIAL exec mask; then every lane copies its region and the end address it got back out
 extern "C" __global__ void k_append(const uint32_t *in, uint32_t *out, uint32_t *ends, const uint32_t *skip) {
-    __shared__ uint32_t lds[64 * 32];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);   // 64 x 32 words
     const int t = threadIdx.x;
     uint32_t w[32];
     for (int j = 0; j < 32; ++j) { w[j] = in[t * 32 + j]; lds[t * 32 + j] = 0; }
@@ -282,7 +284,8 @@ extern "C" __global__ void k_append(const uint32_t *in, uint32_t *out, uint32_t 
 // the 64-bit profiles' compaction: dword w[i] kept where bit 31 - i of flags is set, stored at the XOR-swizzled address, the running
 // address advancing by 8; a lane's region is 256 bytes (the swizzle stays inside a 128-byte block)
 extern "C" __global__ void k_append64(const uint32_t *in, const uint32_t *flags, uint32_t *out, const uint32_t *skip) {
-    __shared__ uint32_t lds[64 * 64];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);   // 64 x 64 words
     const int t = threadIdx.x;
     uint32_t w[32];
     for (int j = 0; j < 32; ++j) w[j] = in[t * 32 + j];
@@ -293,6 +296,7 @@ extern "C" __global__ void k_append64(const uint32_t *in, const uint32_t *flags,
     __syncthreads();
     for (int j = 0; j < 64; ++j) out[t * 64 + j] = lds[t * 64 + j];
 }
+}  // namespace ndzip_hip
 """
 
 
@@ -313,13 +317,94 @@ def asm_objects(tmp_path_factory):
     return out
 
 
-def _both(asm_objects, kernel, make_args):
-    """run `kernel` from both code objects on identical inputs; returns {form: output arrays}"""
+ASM_KERNELS = {  # name: (dynamic LDS bytes, [(argument name, words, "in" | "out")])
+    **{f"k_row{d}": (0, [("data", 1024, "in"), ("out", 1024, "out")]) for d in (1, 2, 4, 8)},
+    "k_scan64": (0, [("data", 128, "in"), ("out", 128, "out")]),
+    "k_pair": (0, [("data", 512, "in"), ("out", 512, "out")]),
+    "k_append": (64 * 32 * 4, [("data", 2048, "in"), ("out", 2048, "out"), ("ends", 64, "out"), ("skip", 64, "in")]),
+    "k_append64": (64 * 64 * 4, [("data", 2048, "in"), ("flags", 64, "in"), ("out", 4096, "out"), ("skip", 64, "in")]),
+}
+
+ASM_HOST_MAIN = r"""
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+// model_blocks <kernel> <dynamic LDS bytes> <file per argument, in order>: inputs are read, outputs (size from the file) written back
+int main(int argc, char **argv) {
+    const std::string k = argv[1];
+    const size_t lds = strtoul(argv[2], nullptr, 10);
+    std::vector<std::vector<uint32_t>> a;
+    for (int i = 3; i < argc; ++i) {
+        FILE *f = fopen(argv[i], "rb");
+        if (!f) return 2;
+        fseek(f, 0, SEEK_END);
+        a.emplace_back(static_cast<size_t>(ftell(f)) / 4);
+        fseek(f, 0, SEEK_SET);
+        if (fread(a.back().data(), 4, a.back().size(), f) != a.back().size()) return 2;
+        fclose(f);
+    }
+    using namespace ndzip_hip;
+    auto p = [&](int i) { return a[i].data(); };
+    if (k == "k_row1") hipLaunchKernelGGL(k_row1, dim3(1), dim3(64), lds, nullptr, p(0), p(1));
+    else if (k == "k_row2") hipLaunchKernelGGL(k_row2, dim3(1), dim3(64), lds, nullptr, p(0), p(1));
+    else if (k == "k_row4") hipLaunchKernelGGL(k_row4, dim3(1), dim3(64), lds, nullptr, p(0), p(1));
+    else if (k == "k_row8") hipLaunchKernelGGL(k_row8, dim3(1), dim3(64), lds, nullptr, p(0), p(1));
+    else if (k == "k_scan64") hipLaunchKernelGGL(k_scan64, dim3(1), dim3(64), lds, nullptr, p(0), p(1));
+    else if (k == "k_pair") hipLaunchKernelGGL(k_pair, dim3(1), dim3(64), lds, nullptr, p(0), p(1));
+    else if (k == "k_append") hipLaunchKernelGGL(k_append, dim3(1), dim3(64), lds, nullptr, p(0), p(1), p(2), p(3));
+    else if (k == "k_append64") hipLaunchKernelGGL(k_append64, dim3(1), dim3(64), lds, nullptr, p(0), p(1), p(2), p(3));
+    else return 3;
+    for (int i = 3; i < argc; ++i) {
+        FILE *f = fopen(argv[i], "wb");
+        if (!f || fwrite(a[i - 3].data(), 4, a[i - 3].size(), f) != a[i - 3].size()) return 4;
+        fclose(f);
+    }
+    return 0;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def model_blocks(tmp_path_factory):
+    """The same kernels on the functional model: host compiler, tests/wavesim -- and therefore the MODEL's own C++ versions of the five
+    blocks (tests/wavesim/gfx950_lds.hpp substitutes the product header there: assembly has no host meaning)."""
+    from tests.wavesim import build as simbuild
+
+    here = os.path.dirname(os.path.abspath(simbuild.__file__))
+    d = tmp_path_factory.mktemp("modelblocks")
+    # (on the model the workgroup's LDS is the array ndzip_hip::smem of its runtime header: the block-scope extern declaration goes)
+    model_source = ASM_SOURCE.replace('extern "C" __global__', "__global__").replace("    extern __shared__ __attribute__((aligned(128))) char smem[];\n", "")
+    assert "    extern __shared__" not in model_source
+    (d / "b.cc").write_text(model_source + ASM_HOST_MAIN)
+    exe = d / "model_blocks"
+    r = subprocess.run([simbuild.CXX, "-std=c++17", "-O1", "-pthread", "-Wno-unknown-attributes", "-I", here, str(d / "b.cc"), os.path.join(here, "wavesim.cc"), "-ldl",
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return str(exe), d
+
+
+def _both(asm_objects, kernel, make_args, model_blocks=None):
+    """run `kernel` from both code objects (interpreter) and on the functional model on identical inputs; returns {form: (outputs, opcodes)}"""
+    lds, spec = ASM_KERNELS[kernel]
     res = {}
     for form, co in asm_objects.items():
         args, outs = make_args()
-        ops = _run(co, kernel, 1, 64, *args)
+        ops = _run(co, kernel, 1, 64, *args, lds=lds)
         res[form] = (outs, ops)
+    if model_blocks is not None:
+        exe, d = model_blocks
+        args, outs = make_args()
+        files = []
+        for i, arr in enumerate(args):
+            f = d / f"{kernel}_{i}.bin"
+            arr.tofile(f)
+            files.append(str(f))
+        r = subprocess.run([exe, kernel, str(lds), *files], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (kernel, r.returncode, r.stdout[-500:], r.stderr[-1500:])
+        for i, arr in enumerate(args):   # read everything back: the outputs are among the arguments
+            arr[...] = np.fromfile(files[i], dtype=np.uint32)
+        res["model"] = (outs, set())
     return res
 
 
@@ -330,7 +415,7 @@ def _pairs64(words, n):
 
 
 @pytest.mark.parametrize("D", [1, 2, 4, 8])
-def test_row_scan_step64_both_forms_are_the_row_shifted_sum(asm_objects, D):
+def test_row_scan_step64_both_forms_are_the_row_shifted_sum(asm_objects, D, model_blocks):
     rng = np.random.default_rng(10 + D)
     data = rng.integers(0, 1 << 32, size=64 * 16, dtype=np.uint64).astype(np.uint32)
     data[:16] = 0xFFFFFFFF  # (carries out of the low dword)
@@ -339,7 +424,7 @@ def test_row_scan_step64_both_forms_are_the_row_shifted_sum(asm_objects, D):
         out = np.zeros(64 * 16, dtype=np.uint32)
         return (data, out), out
 
-    res = _both(asm_objects, f"k_row{D}", make)
+    res = _both(asm_objects, f"k_row{D}", make, model_blocks)
     assert "v_add_co_u32_dpp" in res["assembled"][1] and "v_add_co_u32_dpp" not in res["compiled"][1]
     x = _pairs64(data, 8)
     lane = np.arange(64)
@@ -349,7 +434,7 @@ def test_row_scan_step64_both_forms_are_the_row_shifted_sum(asm_objects, D):
         assert np.array_equal(_pairs64(res[form][0], 8), want), form
 
 
-def test_wave_inclusive_scan64_both_forms_are_the_prefix_sum(asm_objects):
+def test_wave_inclusive_scan64_both_forms_are_the_prefix_sum(asm_objects, model_blocks):
     rng = np.random.default_rng(20)
     data = rng.integers(0, 1 << 32, size=128, dtype=np.uint64).astype(np.uint32)
     data[0:40:2] = 0xFFFFFFFF
@@ -358,7 +443,7 @@ def test_wave_inclusive_scan64_both_forms_are_the_prefix_sum(asm_objects):
         out = np.zeros(128, dtype=np.uint32)
         return (data, out), out
 
-    res = _both(asm_objects, "k_scan64", make)
+    res = _both(asm_objects, "k_scan64", make, model_blocks)
     x = data[0::2].astype(np.uint64) | (data[1::2].astype(np.uint64) << np.uint64(32))
     want = np.cumsum(x, dtype=np.uint64)
     for form in res:
@@ -366,7 +451,7 @@ def test_wave_inclusive_scan64_both_forms_are_the_prefix_sum(asm_objects):
         assert np.array_equal(got, want), form
 
 
-def test_pair_exchange_select4_both_forms(asm_objects):
+def test_pair_exchange_select4_both_forms(asm_objects, model_blocks):
     rng = np.random.default_rng(30)
     data = rng.integers(0, 1 << 32, size=64 * 8, dtype=np.uint64).astype(np.uint32)
 
@@ -374,7 +459,7 @@ def test_pair_exchange_select4_both_forms(asm_objects):
         out = np.zeros(64 * 8, dtype=np.uint32)
         return (data, out), out
 
-    res = _both(asm_objects, "k_pair", make)
+    res = _both(asm_objects, "k_pair", make, model_blocks)
     assert "v_cndmask_b32_dpp" in res["assembled"][1]
     v = data.reshape(64, 8)
     a, b = v[:, :4], v[:, 4:]
@@ -386,7 +471,7 @@ def test_pair_exchange_select4_both_forms(asm_objects):
         assert np.array_equal(res[form][0].reshape(64, 8), want), form
 
 
-def test_lds_append_nonzero_both_forms_under_a_partial_exec_mask(asm_objects):
+def test_lds_append_nonzero_both_forms_under_a_partial_exec_mask(asm_objects, model_blocks):
     rng = np.random.default_rng(40)
     data = rng.integers(0, 1 << 32, size=64 * 32, dtype=np.uint64).astype(np.uint32)
     data[rng.random(64 * 32) < 0.45] = 0
@@ -399,7 +484,7 @@ def test_lds_append_nonzero_both_forms_under_a_partial_exec_mask(asm_objects):
         out, ends = np.zeros(64 * 32, dtype=np.uint32), np.zeros(64, dtype=np.uint32)
         return (data, out, ends, skip), (out, ends)
 
-    res = _both(asm_objects, "k_append", make)
+    res = _both(asm_objects, "k_append", make, model_blocks)
     assert "v_cmpx_ne_u32_e32" in res["assembled"][1] and "v_cmpx_ne_u32_e32" not in res["compiled"][1]
     want, ends = np.zeros((64, 32), dtype=np.uint32), np.zeros(64, dtype=np.uint32)
     for t in range(64):
@@ -415,7 +500,7 @@ def test_lds_append_nonzero_both_forms_under_a_partial_exec_mask(asm_objects):
         assert np.array_equal(out.reshape(64, 32), want) and np.array_equal(got_ends, ends), form
 
 
-def test_lds_append_flagged64_both_forms_under_a_partial_exec_mask(asm_objects):
+def test_lds_append_flagged64_both_forms_under_a_partial_exec_mask(asm_objects, model_blocks):
     rng = np.random.default_rng(50)
     data = rng.integers(0, 1 << 32, size=64 * 32, dtype=np.uint64).astype(np.uint32)
     flags = rng.integers(0, 1 << 32, size=64, dtype=np.uint64).astype(np.uint32)
@@ -427,7 +512,7 @@ def test_lds_append_flagged64_both_forms_under_a_partial_exec_mask(asm_objects):
         out = np.zeros(64 * 64, dtype=np.uint32)
         return (data, flags, out, skip), out
 
-    res = _both(asm_objects, "k_append64", make)
+    res = _both(asm_objects, "k_append64", make, model_blocks)
     assert "v_cmpx_gt_i32_e32" in res["assembled"][1] and "v_bitop3_b32" in res["assembled"][1]
     want = np.zeros((64, 64), dtype=np.uint32)
     for t in range(64):
