@@ -697,3 +697,51 @@ def test_shuffles_and_ballots_model_interpreter_and_the_definition(tmp_path):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
     out_m = np.fromfile(tmp_path / "out.bin", dtype=np.uint32).reshape(64, 12)
     assert np.array_equal(out_m, want), np.argwhere(out_m != want)[:6]
+
+
+ATOMICS_SOURCE = r"""
+#include <hip/hip_runtime.h>
+#include <cstdint>
+// tickets drawn by one lane per wavefront (the compress kernels' scheme), an exchange chain, a fetch-or, and v_readfirstlane under a
+// partial EXEC mask (the first ACTIVE lane's value)
+extern "C" __global__ void k_atomics(uint32_t *counter, uint32_t *tickets, uint32_t *word, uint32_t *seen, uint32_t *flags, const uint32_t *in,
+        const uint32_t *skip, uint32_t *first) {
+    const int t = threadIdx.x, wave = blockIdx.x * (blockDim.x / 64) + t / 64;
+    if ((t & 63) == 0) {
+        tickets[wave] = atomicAdd(counter, 1u);                       // returning atomic: every wavefront a distinct ticket
+        seen[wave] = atomicExch(word, 1000u + wave);                   // the chain of previous values ends in the initial one
+        atomicOr(flags, 1u << (wave & 31));
+    }
+    const uint32_t v = in[blockIdx.x * blockDim.x + t];
+    first[blockIdx.x * blockDim.x + t] = 0xeeeeeeeeu;
+    if (!skip[t & 63]) first[blockIdx.x * blockDim.x + t] = __builtin_amdgcn_readfirstlane(v);
+}
+"""
+
+
+def test_returning_atomics_and_readfirstlane_under_a_partial_exec_mask(tmp_path):
+    from tests import gfx950_exec as gx
+
+    (tmp_path / "a.hip").write_text(ATOMICS_SOURCE)
+    co = tmp_path / "a.hsaco"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "--genco", "--no-gpu-bundle-output", str(tmp_path / "a.hip"), "-o", str(co)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    grid, block = 5, 128
+    waves = grid * block // 64
+    rng = np.random.default_rng(80)
+    v = rng.integers(0, 1 << 32, size=grid * block, dtype=np.uint64).astype(np.uint32)
+    skip = (rng.random(64) < 0.5).astype(np.uint32)
+    skip[:3] = 1                                     # lanes 0-2 are inactive: the first active lane is not lane 0
+    counter, word, flags = np.array([7], dtype=np.uint32), np.array([42], dtype=np.uint32), np.array([0], dtype=np.uint32)
+    tickets, seen, first = np.zeros(waves, dtype=np.uint32), np.zeros(waves, dtype=np.uint32), np.zeros(grid * block, dtype=np.uint32)
+    ops = _run(gx.CodeObject(str(co)), "k_atomics", grid, block, counter, tickets, word, seen, flags, v, skip, first)
+    assert "v_readfirstlane_b32" in ops and any(o.startswith("global_atomic_add") for o in ops) and any(o.startswith("global_atomic_swap") for o in ops)
+    assert sorted(tickets.tolist()) == list(range(7, 7 + waves)) and int(counter[0]) == 7 + waves
+    # the exchange chain: every wavefront saw the initial value or another wavefront's, each exactly once, and the last writer's is left
+    values = [42] + [1000 + w for w in range(waves)]
+    assert sorted(seen.tolist() + [int(word[0])]) == sorted(values)
+    assert int(flags[0]) == sum(1 << (w & 31) for w in set(w & 31 for w in range(waves)))
+    lead = int(np.flatnonzero(skip == 0)[0])
+    for w0 in range(0, grid * block, 64):
+        want = np.where(skip.astype(bool), np.uint32(0xEEEEEEEE), v[w0 + lead])
+        assert np.array_equal(first[w0:w0 + 64], want)
