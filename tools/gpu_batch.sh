@@ -109,8 +109,9 @@ poll)
     if [ -n "$(git status --porcelain ndzip_amd bench.py tests include __graft_entry__.py oracle tools/gpu_batch.sh tools/pmc.sh tools/bench_configs.sh)" ]; then
       echo "$(date +%T) skip: uncommitted edits"; sleep 120; continue
     fi
-    lib=ndzip_amd/libndzip_hip.so
-    if [ ! -f $lib ] || [ -n "$(find ndzip_amd/csrc ndzip_amd/build.py -newer $lib -type f | grep -v _build | head -1)" ]; then
+    lib=ndzip_amd/libndzip_hip.so; rccl=ndzip_amd/libndzip_hip_rccl.so   # (device code + C ABI; the host-only sharded library)
+    if [ ! -f $lib ] || [ ! -f $rccl ] || [ -n "$(find ndzip_amd/csrc ndzip_amd/build.py -newer $lib -type f \( -name '*.hip' -o -name '*.hpp' -o -name '*.inl' -o -name build.py \) | grep -v _build | head -1)" ] \
+       || [ -n "$(find ndzip_amd/csrc -newer $rccl -type f -name '*.cc' | head -1)" ]; then
       echo "$(date +%T) skip: library stale"; sleep 120; continue
     fi
     /usr/local/graft/bin/gpurun --timeout 3400 -- "bash tools/gpu_batch.sh $what $tag" > /tmp/gpurun_$tag.log 2>&1
