@@ -745,3 +745,63 @@ def test_returning_atomics_and_readfirstlane_under_a_partial_exec_mask(tmp_path)
     for w0 in range(0, grid * block, 64):
         want = np.where(skip.astype(bool), np.uint32(0xEEEEEEEE), v[w0 + lead])
         assert np.array_equal(first[w0:w0 + 64], want)
+
+
+MEMORY_SOURCE = r"""
+#include <hip/hip_runtime.h>
+#include <cstdint>
+struct u3 { uint32_t a, b, c; };
+// data movement in every width and pairing the compiler likes to use: 4 / 8 / 12 / 16-byte global accesses, LDS reads and writes that it
+// fuses into ds_read2_b32 / ds_read2_b64 / ds_read2st64_b32 / ds_write2_* when two accesses sit a constant stride apart
+extern "C" __global__ void k_memory(const uint32_t *in, uint32_t *out) {
+    __shared__ uint32_t a[2048];
+    __shared__ uint2 b[512];
+    const int t = threadIdx.x;                                   // 128 work-items
+    const uint4 q = reinterpret_cast<const uint4 *>(in)[t];      // words 0 .. 511
+    const uint2 d = reinterpret_cast<const uint2 *>(in + 512)[t];  // 512 .. 767
+    const u3 e = reinterpret_cast<const u3 *>(in + 768)[t];      // 768 .. 1151
+    a[t] = q.x; a[t + 64 * 4] = q.y;                             // a pair 256 words apart: ds_write2st64_b32
+    a[1024 + 2 * t] = q.z; a[1025 + 2 * t] = q.w ^ 1u;           // neighbours: ds_write2_b32 / ds_write_b64
+    b[t] = d; b[t + 128] = make_uint2(e.a, e.b);                 // 8-byte stores 1 KiB apart: ds_write2st64_b64
+    a[1536 + t] = e.c;
+    __syncthreads();
+    const uint32_t r0 = a[(t * 5) & 127] + a[((t * 5) & 127) + 256];     // ds_read2st64_b32
+    const uint2 r1 = b[127 - t], r2 = b[255 - t];                         // ds_read2st64_b64 or two b64
+    const uint32_t r3 = a[1536 + ((t + 1) & 127)], r4 = a[1536 + ((t + 2) & 127)];
+    uint4 o;
+    o.x = r0; o.y = r1.x ^ r2.y; o.z = r1.y + r2.x; o.w = r3 - r4;
+    reinterpret_cast<uint4 *>(out)[t] = o;
+    u3 p{a[1024 + 2 * ((t + 3) & 127)], a[1025 + 2 * ((t + 7) & 127)], e.c};
+    reinterpret_cast<u3 *>(out + 512)[t] = p;
+}
+"""
+
+
+def test_memory_operations_in_every_width_the_compiler_pairs(tmp_path):
+    from tests import gfx950_exec as gx
+
+    (tmp_path / "m.hip").write_text(MEMORY_SOURCE)
+    co = tmp_path / "m.hsaco"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "--genco", "--no-gpu-bundle-output", str(tmp_path / "m.hip"), "-o", str(co)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(90)
+    x = rng.integers(0, 1 << 32, size=1152, dtype=np.uint64).astype(np.uint32)
+    out = np.zeros(512 + 384, dtype=np.uint32)
+    ops = _run(gx.CodeObject(str(co)), "k_memory", 1, 128, x, out)
+    wide = {o for o in ops if o.startswith(("ds_read2", "ds_write2", "global_load_dwordx", "global_store_dwordx", "ds_read_b64", "ds_write_b64", "ds_read_b128"))}
+    assert any(o.startswith("ds_read2") or o.startswith("ds_write2") for o in wide) and "global_load_dwordx4" in wide and "global_load_dwordx3" in wide, sorted(wide)
+    t = np.arange(128)
+    q, d, e = x[:512].reshape(128, 4), x[512:768].reshape(128, 2), x[768:].reshape(128, 3)
+    a = np.zeros(2048, dtype=np.uint32)
+    a[t], a[t + 256] = q[:, 0], q[:, 1]
+    a[1024 + 2 * t], a[1025 + 2 * t] = q[:, 2], q[:, 3] ^ np.uint32(1)
+    b = np.zeros((512, 2), dtype=np.uint32)
+    b[t], b[t + 128] = d, e[:, :2]
+    a[1536 + t] = e[:, 2]
+    r0 = a[(t * 5) & 127] + a[((t * 5) & 127) + 256]
+    r1, r2 = b[127 - t], b[255 - t]
+    r3, r4 = a[1536 + ((t + 1) & 127)], a[1536 + ((t + 2) & 127)]
+    want = np.stack([r0, r1[:, 0] ^ r2[:, 1], r1[:, 1] + r2[:, 0], r3 - r4], axis=1).astype(np.uint32)
+    assert np.array_equal(out[:512].reshape(128, 4), want)
+    want3 = np.stack([a[1024 + 2 * ((t + 3) & 127)], a[1025 + 2 * ((t + 7) & 127)], e[:, 2]], axis=1)
+    assert np.array_equal(out[512:].reshape(128, 3), want3)
