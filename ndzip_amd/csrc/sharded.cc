@@ -280,16 +280,15 @@ int create(int dtype, int dims, const uint32_t *global_extent, uint32_t rank, ui
 int local_all_gather_u32(void *ctx, const uint32_t *d_send, uint32_t *d_recv, size_t count, void *hip_stream) {
     auto *c = static_cast<local_rank *>(ctx);
     auto stream = static_cast<hipStream_t>(hip_stream);
-    if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+    int rc = hipStreamSynchronize(stream) == hipSuccess ? 0 : 1;  // (a failing rank still keeps both rendezvous: nobody is left waiting)
     c->group->send[c->rank] = d_send;
     c->group->wait();
-    int rc = 0;
     for (uint32_t r = 0; r < c->group->world && rc == 0; ++r) {
         // (hipMemcpyDefault: the runtime infers both sides from the unified address space -- rank r's buffer may live on another GPU)
         if (hipMemcpyAsync(d_recv + r * count, c->group->send[r], count * sizeof(uint32_t), hipMemcpyDefault, stream) != hipSuccess) rc = 2;
     }
     if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess) rc = 3;
-    c->group->wait();  // nobody overwrites its send buffer before everybody has read it (reached even on an error: no rank is left waiting)
+    c->group->wait();  // nobody overwrites its send buffer before everybody has read it
     return rc;
 }
 
