@@ -78,6 +78,10 @@ explain)
   (timeout 400 bash tools/ab.sh "$V" --config 1 2>&1) > ${O}_ab_variants_cfg1.txt
   for w in 0 3 2 1; do echo -n "workgroups per CU $w: "; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compress-only --workgroups-per-cu $w 2>/dev/null | tail -1 | frac_line; done > ${O}_workgroups_per_cu.txt 2>&1
   cat ${O}_workgroups_per_cu.txt
+  # the same sweep on cfg 1 (1D f32 16 Mi = 2 048 tiles: two per workgroup at 4 per CU, so fill + drain are most of the launch -- round 1: 0.38 of peak):
+  # fewer, longer-lived workgroups trade occupancy for pipeline depth there
+  for w in 0 3 2 1; do echo -n "cfg 1, workgroups per CU $w: "; python bench.py --config 1 --steps 50 --warmup 5 --no-cpu-baseline --compress-only --workgroups-per-cu $w 2>/dev/null | tail -1 | frac_line; done > ${O}_workgroups_per_cu_cfg1.txt 2>&1
+  cat ${O}_workgroups_per_cu_cfg1.txt
   (AB_MODE=both timeout 500 bash tools/ab.sh "$V" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
   (AB_MODE=both timeout 500 bash tools/ab.sh "$V" --shape 512,512,512 --dtype float64 2>&1) > ${O}_ab_variants_f64_3d.txt
   cat ${O}_ab_variants_f64_2d.txt ${O}_ab_variants_f64_3d.txt
@@ -123,7 +127,7 @@ poll)
   ;;
 collect)
   dst=${3:-$tag}
-  for f in rocminfo smoke gputest variant_parity bench_n1.json bench_n1_native configs kernel_times_f64 workgroups_per_cu rocprofv3_summary rocprofv3_summary_f64_2d \
+  for f in rocminfo smoke gputest variant_parity bench_n1.json bench_n1_native configs kernel_times_f64 workgroups_per_cu workgroups_per_cu_cfg1 rocprofv3_summary rocprofv3_summary_f64_2d \
            rocprofv3_summary_f64_3d_decode_256 rocprofv3_summary_f64_3d_decode_128 ab_variants ab_variants_cfg1 ab_variants_f64_2d \
            ab_variants_f64_3d phase_timing two_process_stress; do
     for ext in "" .txt; do
