@@ -5,7 +5,8 @@ as b; b.build()") when running several seeds side by side.  Round 3: seeds 11-14
 AddressSanitizer build of the model (LD_PRELOAD of the sanitizer runtime, WAVESIM_VARIANT=asan as in tests/test_wavesim_asan.py): clean.
 Second session of round 3 (dense f64 decoder path, bitop3 complement, backward f32 gather): seeds 51-54 x 600, all equal.
 Fourth session of round 3 (64-bit rotl1 / rotr1 as two v_alignbit_b32): seeds 61-64 x 300, all equal.
-Round 5 (EXEC-masked f64 compaction + dense path, swizzled f32 3D store rows, post-B3 reordering): seeds 141-144 x 400, all equal."""
+Round 5 (EXEC-masked f64 compaction + dense path, swizzled f32 3D store rows, post-B3 reordering): seeds 141-144 x 400, all equal.
+Round 6 (the model itself changed: inactive DPP source lanes, shuffle width; kernels unchanged): seeds 671-674 x 1500, all equal."""
 import sys, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
