@@ -85,6 +85,12 @@ explain)
   (AB_MODE=both timeout 500 bash tools/ab.sh "$V" --config 3 2>&1) > ${O}_ab_variants_f64_2d.txt
   (AB_MODE=both timeout 500 bash tools/ab.sh "$V" --shape 512,512,512 --dtype float64 2>&1) > ${O}_ab_variants_f64_3d.txt
   cat ${O}_ab_variants_f64_2d.txt ${O}_ab_variants_f64_3d.txt
+  # stage attribution by subtraction on the shipped f32 compress pipeline (knobs.so = HEAD + run-time ablation switches: no look-back /
+  # no copy-out / no plane writes, and the resident-workgroup cap) -- round 1's method (docs/rounds.md section 5), cfg 2 and cfg 1
+  if [ -f ndzip_amd/_variants/knobs.so ]; then
+    (echo "== cfg 2"; timeout 300 bash tools/ablate.sh; echo "== cfg 1"; timeout 300 bash tools/ablate.sh --config 1) > ${O}_ablation.txt 2>&1
+    cat ${O}_ablation.txt
+  fi
   if [ -f ndzip_amd/_variants/timing.so ]; then
     (NDZIP_HIP_EXP=16 timeout 300 python bench.py --lib $PWD/ndzip_amd/_variants/timing.so --steps 3 --warmup 1 --no-cpu-baseline --compress-only 2>&1 | tail -40) > ${O}_phase_timing.txt
     tail -20 ${O}_phase_timing.txt
@@ -129,7 +135,7 @@ collect)
   dst=${3:-$tag}
   for f in rocminfo smoke gputest variant_parity bench_n1.json bench_n1_native configs kernel_times_f64 workgroups_per_cu workgroups_per_cu_cfg1 rocprofv3_summary rocprofv3_summary_f64_2d \
            rocprofv3_summary_f64_3d_decode_256 rocprofv3_summary_f64_3d_decode_128 ab_variants ab_variants_cfg1 ab_variants_f64_2d \
-           ab_variants_f64_3d phase_timing two_process_stress; do
+           ab_variants_f64_3d ablation phase_timing two_process_stress; do
     for ext in "" .txt; do
       [ -f "gpurun_out/${tag}_$f$ext" ] && cp "gpurun_out/${tag}_$f$ext" "profiles/${dst}_$f$ext"
     done
