@@ -73,3 +73,13 @@ def test_cpp_sharded_host_is_clean_under_address_sanitizer():
     assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "AddressSanitizer" not in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     m = re.search(r"(\d+) passed", tail)
     assert m and int(m.group(1)) >= 4, tail
+
+
+def test_decoders_stay_in_bounds_on_corrupt_bodies():
+    """A decompressor reads streams it did not write.  Header entries are validated / bounded elsewhere (test_wavesim_codec.py, the
+    host-side ndzip_hip_stream_words); here the header is VALID and the bodies are not: heads that claim all planes of a chunk whose run is
+    short, random words, all ones, bit flips -- through every decoder kernel (both 64-bit mappings, bounded and unbounded entry points) on
+    the sanitised model.  What comes out is garbage by definition; the property is that nothing is read or written outside a buffer."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mp", "corrupt_bodies.py"), "5", "4"], cwd=ROOT, env=asan_env(), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and r.stdout.strip().startswith("ok "), r.stdout[-1000:] + r.stderr[-3000:]
+    assert int(r.stdout.split()[1]) >= 60
