@@ -738,22 +738,27 @@ _DPP_KEYS = ("quad_perm", "row_shl", "row_shr", "row_ror", "row_bcast", "row_mir
 _SDWA_SEL = {"BYTE_0": (0, 8), "BYTE_1": (8, 8), "BYTE_2": (16, 8), "BYTE_3": (24, 8), "WORD_0": (0, 16), "WORD_1": (16, 16), "DWORD": (0, 32)}
 
 
-def _sdwa_src(x, sel):
+def _sdwa_src(x, sel, sext=False):
     sh, bits = _SDWA_SEL[sel]
     x = np.broadcast_to(np.asarray(x, dtype=np.uint32), (64,))
-    return (x >> np.uint32(sh)) & np.uint32((1 << bits) - 1) if bits < 32 else x
+    if bits == 32:
+        return x
+    f = (x >> np.uint32(sh)) & np.uint32((1 << bits) - 1)
+    if sext:  # sext(vN): the selected byte / word is sign-extended
+        f = np.where(f >> np.uint32(bits - 1), f | np.uint32((0xFFFFFFFF << bits) & 0xFFFFFFFF), f)
+    return f
 
 
 def _valu(nsrc, fn, name=None):
     def h(w, i):
-        srcs = [w.rv32(a) for a in i.args[1:1 + nsrc]]
+        srcs = [w.rv32(a[5:-1] if a.startswith("sext(") else a) for a in i.args[1:1 + nsrc]]
         mask = None
         if i.op.endswith("_dpp"):
             srcs[0], mask = _dpp_source(w, i, srcs[0])
         if i.op.endswith("_sdwa"):  # sub-dword source selection (zero-extended), full-dword destination only
-            if i.mods.get("dst_sel", "DWORD") != "DWORD" or any(a.startswith(("sext(", "-", "|")) for a in i.args[1:]):
+            if i.mods.get("dst_sel", "DWORD") != "DWORD" or any(a.startswith(("-", "|")) for a in i.args[1:]):
                 raise Unsupported(i.text)
-            srcs = [_sdwa_src(x, i.mods.get(f"src{k}_sel", "DWORD")) for k, x in enumerate(srcs)]
+            srcs = [_sdwa_src(x, i.mods.get(f"src{k}_sel", "DWORD"), i.args[1 + k].startswith("sext(")) for k, x in enumerate(srcs)]
         w.wv32(i.args[0], fn(*[np.asarray(s, dtype=np.uint32) for s in srcs]), mask)
     return h
 
@@ -802,7 +807,9 @@ _reg("v_bcnt_u32_b32", 2, lambda a, b: np.array([bin(int(x)).count("1") for x in
 def _bfe_i32(a, o, n):
     o = (o & np.uint32(31)).astype(np.int64)
     n = (n & np.uint32(31)).astype(np.int64)
-    x = (np.broadcast_to(a, (64,)).astype(np.int64) >> o) & ((np.int64(1) << n) - 1)
+    # (S0 is SIGNED: the shift is arithmetic, so a field that runs past bit 31 is filled with copies of the sign -- LLVM folds
+    # sbfe(x, off, n) with off + n >= 32 to ashr(x, off); tools/fuzz_interpreter_vs_compiler.py found the logical shift here)
+    x = (np.broadcast_to(a, (64,)).astype(np.uint32).view(np.int32).astype(np.int64) >> o) & ((np.int64(1) << n) - 1)
     sign = (x >> np.maximum(n - 1, 0)) & 1
     x = np.where((n > 0) & (sign == 1), x - (np.int64(1) << n), x)
     return np.where(n == 0, 0, x).astype(np.int64).astype(np.uint32)
@@ -845,7 +852,17 @@ def _(w, i):
 
 def _cndmask(w, i):
     sel = mask_of(w.rs64(i.args[3]) if len(i.args) > 3 else w.vcc)
-    a, b = np.asarray(w.rv32(i.args[1]), dtype=np.uint32), np.asarray(w.rv32(i.args[2]), dtype=np.uint32)
+
+    def src(tok):  # (the VOP3 float modifiers act on the bit pattern: -x flips bit 31, |x| clears it; LLVM selects x ^ 0x80000000 this way)
+        neg = tok.startswith("-") and not tok[1:2].isdigit()   # (-1 is an inline constant, -v4 a modifier)
+        tok = tok[1:] if neg else tok
+        ab = tok.startswith("|") and tok.endswith("|")
+        tok = tok[1:-1] if ab else tok
+        x = np.asarray(w.rv32(tok), dtype=np.uint32)
+        x = x & np.uint32(0x7FFFFFFF) if ab else x
+        return x ^ np.uint32(0x80000000) if neg else x
+
+    a, b = src(i.args[1]), src(i.args[2])
     mask = None
     if i.op.endswith("_dpp"):
         a, mask = _dpp_source(w, i, a)
@@ -917,6 +934,113 @@ def _(w, i):
     w.wmask(i.args[1], r < p)
 
 
+# ---- instructions the product's kernels do not contain; here so that tools/fuzz_interpreter_vs_compiler.py can run what the
+# compiler emits for arbitrary integer HIP code (each one is held against the compiler's own output by that tool) ----
+
+def _ffbh_u32(a):
+    a = np.broadcast_to(a, (64,)).astype(np.uint64)
+    out = np.full(64, 0xFFFFFFFF, dtype=np.uint32)
+    for k in range(64):
+        v = int(a[k])
+        if v:
+            out[k] = 32 - v.bit_length()
+    return out
+
+
+def _ffbl_b32(a):
+    a = np.broadcast_to(a, (64,)).astype(np.uint64)
+    out = np.full(64, 0xFFFFFFFF, dtype=np.uint32)
+    for k in range(64):
+        v = int(a[k])
+        if v:
+            out[k] = (v & -v).bit_length() - 1
+    return out
+
+
+def _bfrev(a):
+    a = np.broadcast_to(a, (64,)).astype(np.uint32).copy()
+    a = ((a >> np.uint32(1)) & np.uint32(0x55555555)) | ((a & np.uint32(0x55555555)) << np.uint32(1))
+    a = ((a >> np.uint32(2)) & np.uint32(0x33333333)) | ((a & np.uint32(0x33333333)) << np.uint32(2))
+    a = ((a >> np.uint32(4)) & np.uint32(0x0F0F0F0F)) | ((a & np.uint32(0x0F0F0F0F)) << np.uint32(4))
+    return a.byteswap()
+
+
+def _s24(x):
+    x = np.broadcast_to(x, (64,)).astype(np.int64) & 0xFFFFFF
+    return np.where(x & 0x800000, x - 0x1000000, x)
+
+
+def _si32(x):
+    return np.broadcast_to(x, (64,)).astype(np.uint32).view(np.int32).astype(np.int64)
+
+
+_reg("v_ffbh_u32", 1, _ffbh_u32)
+_reg("v_ffbl_b32", 1, _ffbl_b32)
+_reg("v_bfrev_b32", 1, _bfrev)
+_reg("v_xnor_b32", 2, lambda a, b: ~(a ^ b))
+_reg("v_alignbyte_b32", 3, lambda hi, lo, s: (((hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)) >> (np.uint64(8) * (s & np.uint32(3)).astype(np.uint64))).astype(np.uint32))
+_reg("v_max_i32", 2, lambda a, b: np.maximum(_si32(a), _si32(b)).astype(np.uint32))
+_reg("v_min_i32", 2, lambda a, b: np.minimum(_si32(a), _si32(b)).astype(np.uint32))
+_reg("v_mul_hi_i32", 2, lambda a, b: ((_si32(a) * _si32(b)) >> 32).astype(np.uint32))
+_reg("v_mul_i32_i24", 2, lambda a, b: (_s24(a) * _s24(b)).astype(np.uint32))
+_reg("v_mul_hi_i32_i24", 2, lambda a, b: ((_s24(a) * _s24(b)) >> 32).astype(np.uint32))
+_reg("v_mul_hi_u32_u24", 2, lambda a, b: (((a & np.uint32(0xFFFFFF)).astype(np.uint64) * (b & np.uint32(0xFFFFFF)).astype(np.uint64)) >> np.uint64(32)).astype(np.uint32))
+_reg("v_mad_i32_i24", 3, lambda a, b, c: ((_s24(a) * _s24(b)).astype(np.uint32) + c))
+
+
+@op("v_ashrrev_i64")
+def _(w, i):
+    sh = np.broadcast_to(np.asarray(w.rv32(i.args[1]), dtype=np.uint32), (64,)).astype(np.int64) & np.int64(63)
+    w.wv64(i.args[0], (np.broadcast_to(np.asarray(w.rv64(i.args[2]), dtype=np.uint64), (64,)).view(np.int64) >> sh).view(np.uint64))
+
+
+@op("s_ashr_i64")
+def _(w, i):
+    r = (_sx(w.rs64(i.args[1]), 64) >> (w.rs32(i.args[2]) & 63)) & M64
+    w.ws64(i.args[0], r)
+    w.scc = int(r != 0)
+
+
+@op("s_bcnt1_i32_b32")
+def _(w, i):
+    r = bin(w.rs32(i.args[1])).count("1")
+    w.ws32(i.args[0], r)
+    w.scc = int(r != 0)
+
+
+@op("s_sext_i32_i16")
+def _(w, i):
+    w.ws32(i.args[0], _sx(w.rs32(i.args[1]) & 0xFFFF, 16) & M32)
+
+
+@op("s_sext_i32_i8")
+def _(w, i):
+    w.ws32(i.args[0], _sx(w.rs32(i.args[1]) & 0xFF, 8) & M32)
+
+
+@op("v_mad_i64_i32")
+def _(w, i):
+    a, b = _si32(np.asarray(w.rv32(i.args[2]), dtype=np.uint32)), _si32(np.asarray(w.rv32(i.args[3]), dtype=np.uint32))
+    c = np.broadcast_to(np.asarray(w.rv64(i.args[4]), dtype=np.uint64), (64,))
+    p = (a * b).view(np.uint64)
+    r = p + c
+    w.wv64(i.args[0], r)
+    # (the carry-out pair is written by the instruction; the compiler never reads it after a signed multiply-add)
+    w.wmask(i.args[1], np.zeros(64, dtype=bool))
+
+
+@op("s_flbit_i32_b64")
+def _(w, i):
+    v = w.rs64(i.args[1])
+    w.ws32(i.args[0], 64 - v.bit_length() if v else M32)
+
+
+@op("s_flbit_i32_b32")
+def _(w, i):
+    v = w.rs32(i.args[1])
+    w.ws32(i.args[0], 32 - v.bit_length() if v else M32)
+
+
 @op("v_mov_b64_e32", "v_mov_b64")
 def _(w, i):
     w.wv64(i.args[0], np.broadcast_to(np.asarray(w.rv64(i.args[1]), dtype=np.uint64), (64,)))
@@ -977,15 +1101,15 @@ def _(w, i):
 
 @op("v_mbcnt_lo_u32_b32")
 def _(w, i):
-    m = w.rs32(i.args[1])
-    cnt = np.array([bin(m & ((1 << min(l, 32)) - 1)).count("1") for l in range(64)], dtype=np.uint32)
+    m = np.broadcast_to(np.asarray(w.rv32(i.args[1]), dtype=np.uint32), (64,))  # (a mask per lane when the source is a VGPR)
+    cnt = np.array([bin(int(m[l]) & ((1 << min(l, 32)) - 1)).count("1") for l in range(64)], dtype=np.uint32)
     w.wv32(i.args[0], cnt + np.asarray(w.rv32(i.args[2]), dtype=np.uint32))
 
 
 @op("v_mbcnt_hi_u32_b32")
 def _(w, i):
-    m = w.rs32(i.args[1])
-    cnt = np.array([bin(m & ((1 << max(l - 32, 0)) - 1)).count("1") for l in range(64)], dtype=np.uint32)
+    m = np.broadcast_to(np.asarray(w.rv32(i.args[1]), dtype=np.uint32), (64,))
+    cnt = np.array([bin(int(m[l]) & ((1 << max(l - 32, 0)) - 1)).count("1") for l in range(64)], dtype=np.uint32)
     w.wv32(i.args[0], cnt + np.asarray(w.rv32(i.args[2]), dtype=np.uint32))
 
 
@@ -1018,7 +1142,7 @@ def _cvt_u32_f32(a):
     return f.astype(np.uint64).astype(np.uint32)
 
 
-_reg("v_cvt_u32_f32", 1, _cvt_u32_f32)
+_reg("v_cvt_u32_f32", 1, _quiet(_cvt_u32_f32))
 
 
 @op("v_fmac_f32_e32", "v_fmac_f32_e64", "v_fmac_f32")
@@ -1158,6 +1282,22 @@ def _(w, i):
     data = np.broadcast_to(np.asarray(w.rv32(i.args[2]), dtype=np.uint32), (64,))
     act = mask_of(w.exec)
     w.wv32(i.args[0], np.where(act[src_lane], data[src_lane], np.uint32(0)))  # (an inactive source lane contributes 0)
+
+
+@op("ds_permute_b32")
+def _(w, i):
+    # the push form: every ACTIVE lane sends its data to lane (addr >> 2) & 63; a lane nobody sends to reads 0; of several senders
+    # to one lane the highest-numbered wins (not among the product's instructions: here for tools/fuzz_interpreter_vs_compiler.py)
+    off = int(i.mods.get("offset", "0"), 0)
+    addr = np.broadcast_to(np.asarray(w.rv32(i.args[1]), dtype=np.uint32), (64,)) + np.uint32(off)
+    dst_lane = ((addr >> np.uint32(2)) & np.uint32(63)).astype(np.int64)
+    data = np.broadcast_to(np.asarray(w.rv32(i.args[2]), dtype=np.uint32), (64,))
+    act = mask_of(w.exec)
+    out = np.zeros(64, dtype=np.uint32)
+    for l in range(64):
+        if act[l]:
+            out[dst_lane[l]] = data[l]
+    w.wv32(i.args[0], out)
 
 
 # ---- global memory ------------------------------------------------------------------------------------------------------------------

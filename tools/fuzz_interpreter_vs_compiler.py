@@ -1,0 +1,490 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the instruction-level interpreter (tests/gfx950_exec.py) against the compiler.
+
+Every offline statement of the form "the BUILT gfx950 code objects reproduce the oracle" rests on the interpreter's reading of the
+ISA.  tests/test_interpreter_vs_compiler.py holds it against a handful of hand-written kernels; this tool widens that to RANDOM
+programs: each case generates one HIP kernel out of language-defined building blocks --
+
+  * 32- and 64-bit integer arithmetic, shifts, rotates, comparisons and selects, signed forms, widening multiplies,
+    popcount / clz / ctz / bit reverse / byte swap, conversions,
+  * wavefront crossings (__shfl, __shfl_xor, __shfl_up, __shfl_down with widths, __ballot, __any / __all),
+  * LDS exchanges through __syncthreads with 4-, 8- and 16-byte accesses at permuted addresses,
+  * divergent if / else regions and data-dependent loops with early exits,
+  * global loads of 4, 8 and 16 bytes,
+  * with --intrinsics, the gfx950 builtins the product's kernels lean on (perm, alignbit, alignbyte, ubfe / sbfe, mbcnt, ds_bpermute,
+    ds_permute, readlane, readfirstlane), whose host meaning is written here from the ISA manual's pseudo-code --
+
+compiles it TWICE: by hipcc for gfx950 (executed by the interpreter, with its hazard and s_waitcnt checkers on -- compiler output
+must never trip them) and, restated over arrays of all work-items, by clang++ for the host (executed natively).  The two results
+must be the same words.  Kernels in which the compiler used an instruction the interpreter does not know are counted and named,
+not failed.
+
+    python3 tools/fuzz_interpreter_vs_compiler.py --seed 1 --cases 100 [--opt O1|O2|O3] [--keep DIR]
+"""
+import argparse
+import collections
+import ctypes as C
+import os
+import random
+import struct
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HIPCC = "/opt/rocm/bin/hipcc"
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+BLOCK, GRID = 256, 2
+N = BLOCK * GRID
+NIN = 6  # input planes of N words
+
+
+class Gen:
+    """One random program.  A statement is (kind, payload); expressions are format strings over {name} placeholders so that the
+    device text (scalars) and the host text (arrays indexed by [i]) are the same characters."""
+
+    def __init__(self, rng: random.Random, intrinsics: bool = False):
+        self.r = rng
+        self.intrinsics = intrinsics
+        self.v32 = ["a", "b", "c", "d"]
+        self.v64 = ["p", "q"]
+        self.n = 0
+        self.stmts = []
+
+    def new(self, wide: bool) -> str:
+        self.n += 1
+        name = f"{'w' if wide else 'v'}{self.n}"
+        (self.v64 if wide else self.v32).append(name)
+        return name
+
+    def x32(self) -> str:
+        r = self.r
+        k = r.random()
+        if k < 0.75:
+            return "{" + r.choice(self.v32) + "}"
+        if k < 0.9:
+            return f"{r.choice([0, 1, 2, 3, 5, 31, 32, 63, 64, 255, 256, 0xffff, 0x80000000, 0xffffffff, r.getrandbits(32)]):#x}u"
+        return "(uint32_t) ({" + r.choice(self.v64) + "}" + r.choice(["", " >> 32", " >> 17"]) + ")"
+
+    def x64(self) -> str:
+        r = self.r
+        k = r.random()
+        if k < 0.7:
+            return "{" + r.choice(self.v64) + "}"
+        if k < 0.85:
+            return f"{r.choice([0, 1, 0xffffffff, 0x100000000, 0x8000000000000000, 0xffffffffffffffff, r.getrandbits(64)]):#x}ull"
+        return "(uint64_t) " + self.x32()
+
+    def e32(self) -> str:
+        r = self.r
+        x, y, z = self.x32(), self.x32(), self.x32()
+        k = r.randrange(1, 32)
+        forms = [
+            f"{x} + {y}", f"{x} - {y}", f"{x} * {y}", f"{x} ^ {y}", f"{x} & {y}", f"{x} | {y}", f"~{x}", f"{x} & ~{y}",
+            f"{x} << ({y} & 31u)", f"{x} >> ({y} & 31u)", f"{x} << {k}u", f"{x} >> {k}u",
+            f"({x} << {k}u) | ({x} >> {32 - k}u)", f"({x} << {k}u) | ({y} >> {32 - k}u)",
+            f"(uint32_t) ((int32_t) {x} >> {k})", f"(uint32_t) ((int32_t) {x} >> ({y} & 31u))",
+            f"({x} < {y}) ? {z} : {x}", f"((int32_t) {x} < (int32_t) {y}) ? {y} : {z}", f"({x} == {y}) ? {z} : {y}",
+            f"({x} < {y} ? {x} : {y})", f"({x} > {y} ? {x} : {y})", f"((int32_t) {x} > (int32_t) {y} ? {x} : {y})",
+            f"(uint32_t) __builtin_popcount({x})", f"(uint32_t) __builtin_clz({x} | 1u)", f"(uint32_t) __builtin_ctz({x} | 0x80000000u)",
+            f"__builtin_bitreverse32({x})", f"__builtin_bswap32({x})",
+            f"({x} >> {k % 24}u) & {(1 << r.randrange(1, 9)) - 1:#x}u", f"({x} & {r.getrandbits(32):#x}u) | ({y} & ~{r.getrandbits(32):#x}u)",
+            f"(uint32_t) (((uint64_t) {x} * {y}) >> 32)", f"(uint32_t) (((int64_t) (int32_t) {x} * (int64_t) (int32_t) {y}) >> 32)",
+            f"{x} * {r.choice([3, 5, 9, 17, 0x9e3779b9])}u + {y}", f"({x} + {y}) ^ ({x} >> 1)", f"({x} ^ {y}) & ({y} ^ {z})",
+            f"({x} & {y}) | (~{x} & {z})", f"({x} != 0u) + ({y} != 0u) + ({z} > 7u)",
+            f"(uint32_t) (uint8_t) ({x} >> 8) + ({y} >> 24)",
+            f"(uint32_t) (int32_t) (int16_t) {x}", f"(uint32_t) (int32_t) (int8_t) ({x} >> {r.choice([0, 8, 16])}u)",
+            f"{x} / ({y} | 1u)", f"{x} % ({y} | 1u)",
+        ]
+        if self.intrinsics:  # gfx950 builtins the product's kernels lean on; their host meaning is HOST_PRELUDE's (from the ISA manual)
+            sel = sum(r.choice([0, 1, 2, 3, 4, 5, 6, 7, 0x0c]) << (8 * j) for j in range(4))
+            forms += [
+                f"__builtin_amdgcn_perm({x}, {y}, {sel:#x}u)", f"__builtin_amdgcn_perm({x}, {y}, {sel:#x}u)",
+                f"__builtin_amdgcn_alignbit({x}, {y}, {z})", f"__builtin_amdgcn_alignbit({x}, {y}, {k}u)", f"__builtin_amdgcn_alignbyte({x}, {y}, {z})",
+                f"__builtin_amdgcn_ubfe({x}, {y}, {z})", f"__builtin_amdgcn_ubfe({x}, {k}u, {r.randrange(0, 32)}u)",
+                f"(uint32_t) __builtin_amdgcn_sbfe((int32_t) {x}, {k}u, {r.randrange(0, 32)}u)",
+                f"__builtin_amdgcn_mbcnt_hi({y}, __builtin_amdgcn_mbcnt_lo({x}, {z}))", f"__builtin_amdgcn_mbcnt_lo({x}, 0u)",
+            ]
+        return r.choice(forms)
+
+    def e64(self) -> str:
+        r = self.r
+        x, y = self.x64(), self.x64()
+        s = self.x32()
+        k = r.randrange(1, 64)
+        forms = [
+            f"{x} + {y}", f"{x} - {y}", f"{x} ^ {y}", f"{x} & {y}", f"{x} | {y}", f"~{x}", f"{x} * {y}",
+            f"{x} << ({s} & 63u)", f"{x} >> ({s} & 63u)", f"{x} << {k}u", f"{x} >> {k}u", f"({x} << {k}u) | ({x} >> {64 - k}u)",
+            f"(uint64_t) ((int64_t) {x} >> {k})", f"({x} < {y}) ? {x} : {y}", f"((int64_t) {x} < (int64_t) {y}) ? {y} : {x}",
+            f"(uint64_t) {s} * (uint64_t) {self.x32()}", f"{x} + (uint64_t) {s}", f"({x} << 32) | (uint64_t) {s}",
+            f"(uint64_t) __builtin_popcountll({x})", f"(uint64_t) __builtin_clzll({x} | 1ull)", f"(uint64_t) __builtin_ctzll({x} | 0x8000000000000000ull)",
+            f"(uint64_t) (int64_t) (int32_t) {s}", f"{x} * 0x9e3779b97f4a7c15ull + {y}", f"({x} == {y}) ? 1ull : ({x} ^ {y})",
+        ]
+        return r.choice(forms)
+
+    def plain(self, depth=0):
+        """a work-item-local statement: ('set', name, wide, expr)"""
+        if self.r.random() < 0.3:
+            e = self.e64()                      # (the expression first: a new name must not appear in its own initialiser)
+            return ("set", self.new(True), True, e)
+        e = self.e32()
+        return ("set", self.new(False), False, e)
+
+    def assign_existing(self):
+        wide = self.r.random() < 0.25
+        name = self.r.choice((self.v64 if wide else self.v32)[2 if wide else 4:] or (self.v64 if wide else self.v32))
+        return ("upd", name, wide, self.e64() if wide else self.e32())
+
+    def statement(self):
+        r = self.r
+        k = r.random()
+        if k < 0.50:
+            return self.plain()
+        if k < 0.68:
+            src = r.choice(self.v32) if r.random() < 0.8 else r.choice(self.v64)
+            wide = src in self.v64
+            width = r.choice([64, 64, 64, 32, 16, 8])
+            how = r.choice(["xor", "up", "down", "idx", "idxv"] + (["bperm", "perm", "readlane", "first"] if self.intrinsics and not wide else []))
+            if how in ("bperm", "perm", "readlane", "first"):
+                width = 64
+            delta = r.randrange(1, width) if how != "idx" else r.randrange(0, width)
+            sel = r.choice(self.v32)
+            return ("cross", self.new(wide), wide, src, how, delta, width, sel)
+        if k < 0.74:
+            src = r.choice(self.v32)
+            return ("ballot", self.new(True), src, r.randrange(32))
+        if k < 0.78:
+            src = r.choice(self.v32)
+            return ("vote", self.new(False), src, r.choice(["any", "all"]), r.getrandbits(32) >> r.randrange(20, 32))
+        if k < 0.88:
+            kind = r.choice(["u32", "u32", "u64", "u128"])
+            mul_w = r.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 33, 65, 127, 129, 255])
+            add_w, mul_r, add_r = r.randrange(256), r.randrange(1, 64), r.randrange(256)
+            if kind == "u32":
+                src = r.choice(self.v32)
+                return ("lds32", self.new(False), src, mul_w, add_w, mul_r, add_r)
+            if kind == "u64":
+                src = r.choice(self.v64)
+                return ("lds64", self.new(True), src, mul_w, add_w, mul_r, add_r)
+            srcs = [r.choice(self.v32) for _ in range(4)]
+            return ("lds128", self.new(False), srcs, mul_w, add_w, mul_r, add_r)
+        if k < 0.95:
+            cond = f"({self.x32()} {r.choice(['&', '^', '+'])} {self.x32()}) {r.choice(['& 1u', '& 4u', '> 0x7fffffffu', '< 0x40000000u', '% 3u == 1u'])}"
+            then = [self.assign_existing() for _ in range(r.randrange(1, 4))]
+            other = [self.assign_existing() for _ in range(r.randrange(0, 3))]
+            return ("if", cond, then, other)
+        acc = r.choice(self.v32[4:] or self.v32)
+        trip = f"({self.x32()} & {r.choice([3, 7, 15])}u)"
+        body = r.choice([f"{{{acc}}} * 3u + k", f"{{{acc}}} ^ ({self.x32()} >> (k & 31u))", f"({{{acc}}} << 1) + ({self.x32()} & k)"])
+        stop = f"{{{acc}}} > {r.choice([0xf0000000, 0xc0000000, 0xffffff00]):#x}u" if r.random() < 0.5 else None
+        return ("loop", acc, trip, body, stop)
+
+    def build(self, nstmts: int):
+        self.stmts = [self.statement() for _ in range(nstmts)]
+        return self
+
+
+# The host's meaning of the gfx950 builtins, written from the ISA manual's pseudo-code (V_PERM_B32, V_ALIGNBIT_B32, V_ALIGNBYTE_B32,
+# V_BFE_U32 / V_BFE_I32, V_MBCNT_LO / _HI_U32_B32); `lane` is the work-item's position in its wavefront.
+HOST_PRELUDE = r"""
+#define lane (i & 63u)
+static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    const uint64_t both = ((uint64_t) s0 << 32) | s1; uint32_t d = 0;
+    for (int k = 0; k < 4; ++k) { const uint32_t c = (sel >> (8 * k)) & 0xffu;
+        uint32_t byte = c <= 7 ? (uint32_t) (both >> (8 * c)) & 0xffu : c == 0x0c ? 0u : 0xffu;
+        d |= byte << (8 * k); }
+    return d;
+}
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t) ((((uint64_t) hi << 32) | lo) >> (s & 31u)); }
+static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t) ((((uint64_t) hi << 32) | lo) >> (8u * (s & 3u))); }
+static inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t off, uint32_t n) { off &= 31u; n &= 31u; return n ? (v >> off) & ((1u << n) - 1u) : 0u; }
+static inline int32_t __builtin_amdgcn_sbfe(int32_t v, uint32_t off, uint32_t n) { off &= 31u; n &= 31u; if (!n) return 0;
+    const uint32_t f = (uint32_t) (v >> off) & ((1u << n) - 1u);  /* arithmetic shift: a field past bit 31 is filled with the sign */ return (f >> (n - 1u)) & 1u ? (int32_t) (f | ~((1u << n) - 1u)) : (int32_t) f; }
+#define __builtin_amdgcn_mbcnt_lo(m, add) ((uint32_t) __builtin_popcount((m) & (lane >= 32u ? 0xffffffffu : (1u << lane) - 1u)) + (add))
+#define __builtin_amdgcn_mbcnt_hi(m, add) ((uint32_t) __builtin_popcount((m) & (lane <= 32u ? 0u : (1u << (lane - 32u)) - 1u)) + (add))
+"""
+
+
+def _fmt(expr: str, host: bool) -> str:
+    class M(dict):
+        def __missing__(self, key):
+            return f"{key}[i]" if host else key
+    return expr.format_map(M())
+
+
+def device_source(g: Gen) -> str:
+    o = ["#include <hip/hip_runtime.h>", "#include <cstdint>",
+         'extern "C" __global__ void __launch_bounds__(256) k_fuzz(const uint32_t *in, uint32_t *out) {',
+         "    __shared__ uint32_t l32[256]; __shared__ uint64_t l64[256]; __shared__ uint4 l128[256];",
+         "    const uint32_t t = threadIdx.x, i = blockIdx.x * 256u + t;",
+         f"    uint32_t a = in[i], b = in[i + {N}], c = in[2 * {N} + (i ^ 1u)];",
+         f"    const uint2 pq = ((const uint2 *) (in + 3 * {N}))[i >> 1];",
+         f"    uint32_t d = (i & 1u) ? pq.y : pq.x;",
+         f"    const uint4 four = ((const uint4 *) (in + 4 * {N}))[i >> 2];",
+         f"    uint64_t p = ((uint64_t) four.x << 32) | four.w, q = ((uint64_t) four.y << 32) | (four.z ^ in[5 * {N} + i]);"]
+
+    def emit(s, ind):
+        pad = "    " * ind
+        k = s[0]
+        if k == "set":
+            o.append(f"{pad}{'uint64_t' if s[2] else 'uint32_t'} {s[1]} = {_fmt(s[3], False)};")
+        elif k == "upd":
+            o.append(f"{pad}{s[1]} = {_fmt(s[3], False)};")
+        elif k == "cross":
+            _, name, wide, src, how, delta, width, sel = s
+            ty = "uint64_t" if wide else "uint32_t"
+            cast = "(unsigned long long) " if wide else ""
+            call = {"xor": f"__shfl_xor({cast}{src}, {delta}, {width})", "up": f"__shfl_up({cast}{src}, {delta}u, {width})",
+                    "down": f"__shfl_down({cast}{src}, {delta}u, {width})", "idx": f"__shfl({cast}{src}, {delta}, {width})",
+                    "idxv": f"__shfl({cast}{src}, (int) (({sel} >> 3) & 63u), {width})",
+                    "bperm": f"__builtin_amdgcn_ds_bpermute((int) ({sel} << 2), (int) {src})",
+                    "perm": f"__builtin_amdgcn_ds_permute((int) (((t * {2 * delta + 1}u + 5u) & 63u) << 2), (int) {src})",
+                    "readlane": f"__builtin_amdgcn_readlane((int) {src}, {delta})",
+                    "first": f"__builtin_amdgcn_readfirstlane((int) {src})"}[how]
+            o.append(f"{pad}{ty} {name} = ({ty}) {call};")
+        elif k == "ballot":
+            o.append(f"{pad}uint64_t {s[1]} = __ballot(({s[2]} >> {s[3]}u) & 1u);")
+        elif k == "vote":
+            o.append(f"{pad}uint32_t {s[1]} = (uint32_t) __{s[3]}({s[2]} > {s[4]:#x}u);")
+        elif k in ("lds32", "lds64"):
+            _, name, src, mw, aw, mr, ar = s
+            arr, ty = ("l32", "uint32_t") if k == "lds32" else ("l64", "uint64_t")
+            o.append(f"{pad}{arr}[(t * {mw}u + {aw}u) & 255u] = {src}; __syncthreads();")
+            o.append(f"{pad}{ty} {name} = {arr}[(t * {mr}u + {ar}u) & 255u]; __syncthreads();")
+        elif k == "lds128":
+            _, name, srcs, mw, aw, mr, ar = s
+            o.append(f"{pad}l128[(t * {mw}u + {aw}u) & 255u] = make_uint4({', '.join(srcs)}); __syncthreads();")
+            o.append(f"{pad}const uint4 {name}_q = l128[(t * {mr}u + {ar}u) & 255u]; __syncthreads();")
+            o.append(f"{pad}uint32_t {name} = {name}_q.x ^ ({name}_q.y << 1) ^ ({name}_q.z >> 1) ^ ({name}_q.w * 3u);")
+        elif k == "if":
+            o.append(f"{pad}if ({_fmt(s[1], False)}) {{")
+            for x in s[2]:
+                emit(x, ind + 1)
+            if s[3]:
+                o.append(f"{pad}}} else {{")
+                for x in s[3]:
+                    emit(x, ind + 1)
+            o.append(f"{pad}}}")
+        elif k == "loop":
+            _, acc, trip, body, stop = s
+            o.append(f"{pad}for (uint32_t k = 0, n = {_fmt(trip, False)}; k < n; ++k) {{")
+            o.append(f"{pad}    {acc} = {_fmt(body, False)};")
+            if stop:
+                o.append(f"{pad}    if ({_fmt(stop, False)}) break;")
+            o.append(f"{pad}}}")
+
+    for s in g.stmts:
+        emit(s, 1)
+    o.append("    uint32_t h = 0x811c9dc5u; uint64_t hh = 0xcbf29ce484222325ull;")
+    for idx, v in enumerate(g.v32):
+        o.append(f"    h = (h ^ {v}) * 0x01000193u;")
+        o.append(f"    out[(uint64_t) i * {len(g.v32) + 2 * len(g.v64) + 3} + {idx}] = {v};")
+    base = len(g.v32)
+    for idx, v in enumerate(g.v64):
+        o.append(f"    hh = (hh ^ {v}) * 0x100000001b3ull;")
+        o.append(f"    out[(uint64_t) i * {len(g.v32) + 2 * len(g.v64) + 3} + {base + 2 * idx}] = (uint32_t) {v};")
+        o.append(f"    out[(uint64_t) i * {len(g.v32) + 2 * len(g.v64) + 3} + {base + 2 * idx + 1}] = (uint32_t) ({v} >> 32);")
+    stride = len(g.v32) + 2 * len(g.v64) + 3
+    o.append(f"    out[(uint64_t) i * {stride} + {stride - 3}] = h;")
+    o.append(f"    out[(uint64_t) i * {stride} + {stride - 2}] = (uint32_t) hh;")
+    o.append(f"    out[(uint64_t) i * {stride} + {stride - 1}] = (uint32_t) (hh >> 32);")
+    o.append("}")
+    return "\n".join(o) + "\n"
+
+
+def host_source(g: Gen) -> str:
+    """The same program over arrays of all N work-items: work-item-local statements loop over i; a crossing loops over the 64
+    lanes of each wavefront; an LDS exchange is a scatter then a gather per workgroup."""
+    o = ["#include <cstdint>", "#include <vector>", f"static const uint32_t N = {N};",
+         "struct u4 { uint32_t x, y, z, w; };", HOST_PRELUDE,
+         'extern "C" void k_fuzz_host(const uint32_t *in, uint32_t *out) {',
+         "    std::vector<uint32_t> a(N), b(N), c(N), d(N); std::vector<uint64_t> p(N), q(N);",
+         "    for (uint32_t i = 0; i < N; ++i) {",
+         "        a[i] = in[i]; b[i] = in[i + N]; c[i] = in[2 * N + (i ^ 1u)]; d[i] = in[3 * N + i];",
+         "        const uint32_t *f = in + 4 * N + (i & ~3u);",
+         "        p[i] = ((uint64_t) f[0] << 32) | f[3]; q[i] = ((uint64_t) f[1] << 32) | (f[2] ^ in[5 * N + i]);",
+         "    }"]
+
+    def local(s, ind):
+        pad = "    " * ind
+        k = s[0]
+        if k in ("set", "upd"):
+            o.append(f"{pad}{s[1]}[i] = {_fmt(s[3], True)};")
+        elif k == "if":
+            o.append(f"{pad}if ({_fmt(s[1], True)}) {{")
+            for x in s[2]:
+                local(x, ind + 1)
+            if s[3]:
+                o.append(f"{pad}}} else {{")
+                for x in s[3]:
+                    local(x, ind + 1)
+            o.append(f"{pad}}}")
+        elif k == "loop":
+            _, acc, trip, body, stop = s
+            o.append(f"{pad}for (uint32_t k = 0, n = {_fmt(trip, True)}; k < n; ++k) {{")
+            o.append(f"{pad}    {acc}[i] = {_fmt(body, True)};")
+            if stop:
+                o.append(f"{pad}    if ({_fmt(stop, True)}) break;")
+            o.append(f"{pad}}}")
+
+    for s in g.stmts:
+        k = s[0]
+        if k == "set":
+            o.append(f"    std::vector<{'uint64_t' if s[2] else 'uint32_t'}> {s[1]}(N);")
+        if k in ("set", "upd", "if", "loop"):
+            o.append("    for (uint32_t i = 0; i < N; ++i) {")
+            local(s, 2)
+            o.append("    }")
+        elif k == "cross":
+            _, name, wide, src, how, delta, width, sel = s
+            ty = "uint64_t" if wide else "uint32_t"
+            o.append(f"    std::vector<{ty}> {name}(N);")
+            o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) for (uint32_t l = 0; l < 64; ++l) {")
+            o.append(f"        const uint32_t W = {width}, seg = l & ~(W - 1u), r = l & (W - 1u); uint32_t from;")
+            if how == "xor":
+                o.append(f"        {{ const uint32_t j = l ^ {delta}u; from = j < seg + W ? j : l; }}")   # HIP: index = lane ^ mask; beyond the segment -> self
+            elif how == "up":
+                o.append(f"        from = r >= {delta}u ? l - {delta}u : l;")
+            elif how == "down":
+                o.append(f"        from = r + {delta}u < W ? l + {delta}u : l;")
+            elif how == "idx":
+                o.append(f"        from = seg + ({delta}u & (W - 1u));")
+            elif how == "bperm":
+                o.append(f"        from = {sel}[w0 + l] & 63u;")
+            elif how == "perm":   # a push along a permutation of the lanes: lane s sends to (s * odd + 5) & 63, so l receives from its inverse
+                o.append(f"        from = 0; for (uint32_t s2 = 0; s2 < 64; ++s2) if (((s2 * {2 * delta + 1}u + 5u) & 63u) == l) from = s2;")
+            elif how == "readlane":
+                o.append(f"        from = {delta}u;")
+            elif how == "first":
+                o.append("        from = 0;")
+            else:
+                o.append(f"        from = seg + ((({sel}[w0 + l] >> 3) & 63u) & (W - 1u));")
+            o.append(f"        {name}[w0 + l] = {src}[w0 + from];")
+            o.append("    }")
+        elif k == "ballot":
+            o.append(f"    std::vector<uint64_t> {s[1]}(N);")
+            o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) { uint64_t m = 0;")
+            o.append(f"        for (uint32_t l = 0; l < 64; ++l) m |= (uint64_t) (({s[2]}[w0 + l] >> {s[3]}u) & 1u) << l;")
+            o.append(f"        for (uint32_t l = 0; l < 64; ++l) {s[1]}[w0 + l] = m; }}")
+        elif k == "vote":
+            o.append(f"    std::vector<uint32_t> {s[1]}(N);")
+            o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) { uint32_t n = 0;")
+            o.append(f"        for (uint32_t l = 0; l < 64; ++l) n += {s[2]}[w0 + l] > {s[4]:#x}u;")
+            o.append(f"        for (uint32_t l = 0; l < 64; ++l) {s[1]}[w0 + l] = {'n != 0' if s[3] == 'any' else 'n == 64'}; }}")
+        elif k in ("lds32", "lds64"):
+            _, name, src, mw, aw, mr, ar = s
+            ty = "uint32_t" if k == "lds32" else "uint64_t"
+            o.append(f"    std::vector<{ty}> {name}(N);")
+            o.append(f"    for (uint32_t g0 = 0; g0 < N; g0 += 256) {{ {ty} lds[256];")
+            o.append(f"        for (uint32_t t = 0; t < 256; ++t) lds[(t * {mw}u + {aw}u) & 255u] = {src}[g0 + t];")
+            o.append(f"        for (uint32_t t = 0; t < 256; ++t) {name}[g0 + t] = lds[(t * {mr}u + {ar}u) & 255u]; }}")
+        elif k == "lds128":
+            _, name, srcs, mw, aw, mr, ar = s
+            o.append(f"    std::vector<uint32_t> {name}(N);")
+            o.append("    for (uint32_t g0 = 0; g0 < N; g0 += 256) { u4 lds[256];")
+            o.append(f"        for (uint32_t t = 0; t < 256; ++t) lds[(t * {mw}u + {aw}u) & 255u] = u4{{{', '.join(x + '[g0 + t]' for x in srcs)}}};")
+            o.append(f"        for (uint32_t t = 0; t < 256; ++t) {{ const u4 z = lds[(t * {mr}u + {ar}u) & 255u]; {name}[g0 + t] = z.x ^ (z.y << 1) ^ (z.z >> 1) ^ (z.w * 3u); }} }}")
+    stride = len(g.v32) + 2 * len(g.v64) + 3
+    o.append("    for (uint32_t i = 0; i < N; ++i) { uint32_t h = 0x811c9dc5u; uint64_t hh = 0xcbf29ce484222325ull;")
+    o.append(f"        uint32_t *r = out + (uint64_t) i * {stride};")
+    for idx, v in enumerate(g.v32):
+        o.append(f"        h = (h ^ {v}[i]) * 0x01000193u; r[{idx}] = {v}[i];")
+    base = len(g.v32)
+    for idx, v in enumerate(g.v64):
+        o.append(f"        hh = (hh ^ {v}[i]) * 0x100000001b3ull; r[{base + 2 * idx}] = (uint32_t) {v}[i]; r[{base + 2 * idx + 1}] = (uint32_t) ({v}[i] >> 32);")
+    o.append(f"        r[{stride - 3}] = h; r[{stride - 2}] = (uint32_t) hh; r[{stride - 1}] = (uint32_t) (hh >> 32); }}")
+    o.append("}")
+    return "\n".join(o) + "\n", stride
+
+
+def inputs(rng: np.random.Generator) -> np.ndarray:
+    x = rng.integers(0, 1 << 32, size=NIN * N, dtype=np.uint64).astype(np.uint32)
+    # corner values sprinkled in: zeros, all-ones, sign bits, small numbers
+    special = np.array([0, 1, 2, 0x7fffffff, 0x80000000, 0xffffffff, 0xfffffffe, 31, 32, 63, 64, 0x10000, 0xffff], dtype=np.uint32)
+    where = rng.random(x.size) < 0.15
+    x[where] = special[rng.integers(0, special.size, size=int(where.sum()))]
+    return x
+
+
+def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: bool = False):
+    g = Gen(random.Random(seed), intrinsics).build(nstmts)
+    dev = device_source(g)
+    host, stride = host_source(g)
+    dpath, hpath = os.path.join(workdir, f"case{seed}.hip"), os.path.join(workdir, f"case{seed}_host.cc")
+    open(dpath, "w").write(dev)
+    open(hpath, "w").write(host)
+    co, so = os.path.join(workdir, f"case{seed}.hsaco"), os.path.join(workdir, f"case{seed}_host.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", f"-{opt}", "--genco", "--no-gpu-bundle-output", dpath, "-o", co], capture_output=True, text=True)
+    if r.returncode:
+        return "device-compile", r.stderr[-1500:]
+    r = subprocess.run([CLANG, "-O1", "-shared", "-fPIC", "-std=c++17", hpath, "-o", so], capture_output=True, text=True)
+    if r.returncode:
+        return "host-compile", r.stderr[-1500:]
+    x = inputs(np.random.default_rng(seed))
+    want = np.zeros(N * stride, dtype=np.uint32)
+    L = C.CDLL(so)
+    L.k_fuzz_host(C.c_void_p(x.ctypes.data), C.c_void_p(want.ctypes.data))
+    k = gx.Kernel(gx.CodeObject(co), "k_fuzz")
+    if k.missing:
+        return "unknown-op", sorted(k.missing)
+    got = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32)
+    lds = k.lds_bytes if hasattr(k, "lds_bytes") else 0
+    try:
+        gx.run_grid(k, GRID, BLOCK, lds, struct.pack("<QQ", x.ctypes.data, got.ctypes.data), resident=2, quantum=400)
+    except gx.Unsupported as e:
+        return "unsupported", str(e)
+    except Exception as e:  # a hazard / wait report on compiler output, or an interpreter fault
+        return "interpreter-error", f"{type(e).__name__}: {e}"
+    if np.array_equal(got, want):
+        return "ok", {x.op for x in k.code.values()}
+    bad = np.flatnonzero(got != want)
+    cols = sorted({int(b % stride) for b in bad})
+    names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
+    first = int(bad[0])
+    return "MISMATCH", f"{bad.size} words differ; columns {[names[c] for c in cols][:8]}; first: work-item {first // stride} {names[first % stride]} got {got[first]:#x} want {want[first]:#x}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cases", type=int, default=20)
+    ap.add_argument("--opt", default="O3", choices=["O1", "O2", "O3", "Os"])
+    ap.add_argument("--statements", type=int, default=28)
+    ap.add_argument("--intrinsics", action="store_true", help="also draw from the gfx950 builtins the product's kernels use (host meaning: HOST_PRELUDE)")
+    ap.add_argument("--keep", default=None, help="directory for the generated sources (default: a temporary one)")
+    args = ap.parse_args()
+    from tests import gfx950_exec as gx
+
+    work = args.keep or tempfile.mkdtemp(prefix="fuzz_ivc_")
+    os.makedirs(work, exist_ok=True)
+    tally, ops_seen, unknown, problems = collections.Counter(), set(), collections.Counter(), []
+    t0 = time.time()
+    for n in range(args.cases):
+        seed = args.seed * 100000 + n
+        status, info = run_case(seed, work, args.opt, args.statements, gx, args.intrinsics)
+        tally[status] += 1
+        if status == "ok":
+            ops_seen |= info
+            if not args.keep:
+                for f in os.listdir(work):
+                    if f.startswith(f"case{seed}"):
+                        os.unlink(os.path.join(work, f))
+        elif status == "unknown-op":
+            unknown.update(info)
+        else:
+            problems.append((seed, status, info))
+            print(f"case {seed}: {status}: {info}", flush=True)
+    print(f"seed {args.seed} -{args.opt}{' +intrinsics' if args.intrinsics else ''}: {dict(tally)} in {time.time() - t0:.0f} s; {len(ops_seen)} distinct opcodes executed in agreeing kernels")
+    if unknown:
+        print("  opcodes the interpreter does not know (kernels skipped):", dict(unknown.most_common()))
+    if problems:
+        print(f"  sources of the {len(problems)} problem cases kept in {work}")
+    return 1 if any(s in ("MISMATCH", "interpreter-error") for _, s, _ in problems) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
