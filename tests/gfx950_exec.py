@@ -348,6 +348,10 @@ class Wave:
             return self.vcc
         if tok == "exec":
             return self.exec
+        if tok in _FLOAT_CONST:
+            # (a float inline constant in a 64-bit operand is the DOUBLE of that value: LLVM writes 1 << 62 as `v_mov_b64 v[a:b], 2.0`;
+            # found by tools/fuzz_interpreter_vs_compiler.py -- the product's code objects hold no such operand)
+            return struct.unpack("<Q", struct.pack("<d", float(tok)))[0]
         v = _imm(tok)
         if v is not None:
             return v & M64  # (inline integer constants are sign-extended to 64 bits; a 32-bit literal is zero-extended)

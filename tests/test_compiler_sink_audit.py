@@ -1,0 +1,84 @@
+"""This image's LLVM can sink an LDS load past __syncthreads() (tools/audit_machine_sink.py: found by the differential fuzz of the
+interpreter against the compiler).  Held here on every run:
+
+  * the compiler's own account (MIR before / after its machine-sink pass) shows NO load leaving its block in any of the product's
+    three device units -- so the product's code objects do not carry that race;
+  * the reproducer is the positive control: the audit sees the sunk load, the interpreter runs the resulting code to a wrong
+    answer under a skewed schedule, and with the pass switched off (-mllvm -disable-machine-sink) both are clean.  Should a later
+    compiler stop sinking the load, the control asserts only that the program then runs right."""
+import importlib.util
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("audit_machine_sink", os.path.join(ROOT, "tools", "audit_machine_sink.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("unit", ["kernels_f32", "kernels_f64", "capi"])
+def test_no_load_of_the_product_leaves_its_block(tmp_path, unit):
+    tool = _tool()
+    rows = tool.audit(os.path.join(ROOT, "ndzip_amd", "csrc", unit + ".hip"), tool.PRODUCT_FLAGS, str(tmp_path))
+    assert len(rows) >= 4
+    for name, nmoved, nloads, bad in rows:
+        assert nloads == 0 and not bad, (name, nloads, bad)
+
+
+def _expected(x):
+    n = 512
+    a, b = x[:n].astype(np.uint64), x[n:2 * n].astype(np.uint64)
+    out = np.zeros(2 * n, dtype=np.uint32)
+    for g0 in range(0, n, 256):
+        t = np.arange(256)
+        slot = np.zeros(256, dtype=np.uint64)
+        slot[(t * 11 + 201) & 255] = (a[g0:g0 + 256] << np.uint64(32)) | b[g0:g0 + 256]
+        first = slot[(t * 60 + 241) & 255]
+        xx = a[g0:g0 + 256].astype(np.uint32).copy()
+        bb = b[g0:g0 + 256].astype(np.uint32)
+        for w0 in range(0, 256, 64):
+            ballot = sum(int(bb[w0 + l] & 1) << l for l in range(64))
+            for k in range(ballot & 3):
+                xx[w0:w0 + 64] ^= bb[w0:w0 + 64] >> np.uint32(k)
+        slot = np.zeros(256, dtype=np.uint64)
+        slot[(t * 15 + 249) & 255] = xx.astype(np.uint64)
+        second = slot[(t * 27 + 191) & 255]
+        out[2 * g0:2 * g0 + 512:2] = ((first ^ (first >> np.uint64(32))).astype(np.uint32) + xx)
+        out[2 * g0 + 1:2 * g0 + 512:2] = (second ^ (second >> np.uint64(32))).astype(np.uint32)
+    return out
+
+
+@pytest.mark.parametrize("sink", [True, False])
+def test_reproducer_is_seen_by_the_audit_and_by_the_interpreter(tmp_path, sink):
+    from tests import gfx950_exec as gx
+
+    tool = _tool()
+    src = tmp_path / "rep.hip"
+    src.write_text(tool.REPRODUCER)
+    flags = ["-O3"] + ([] if sink else ["-mllvm", "-disable-machine-sink"])
+    sunk = sum(len(bad) for _, _, _, bad in tool.audit(str(src), flags, str(tmp_path))) if sink else 0  # (pass off: nothing to dump)
+    co = tmp_path / "rep.hsaco"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", *flags, "--genco", "--no-gpu-bundle-output", str(src), "-o", str(co)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    x = np.random.default_rng(7).integers(0, 1 << 32, size=1024, dtype=np.uint64).astype(np.uint32)
+    got = np.zeros(1024, dtype=np.uint32)
+    k = gx.Kernel(gx.CodeObject(str(co)), "k_sink")
+    assert not k.missing, k.missing
+    gx.run_grid(k, 2, 256, 0, struct.pack("<QQ", x.ctypes.data, got.ctypes.data), resident=2, quantum=400)  # (one wavefront runs far ahead of the next)
+    right = np.array_equal(got, _expected(x))
+    if not sink:
+        assert sunk == 0 and right
+    elif sunk:
+        assert not right, "the load was sunk past the barrier, yet the skewed schedule did not expose the race"
+    else:
+        assert right  # (a compiler that no longer sinks the load)

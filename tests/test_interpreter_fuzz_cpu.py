@@ -27,7 +27,7 @@ def test_random_kernels_agree_with_their_host_build(tmp_path, intrinsics, opt, f
     for seed in range(first, first + 10):
         status, info = tool.run_case(seed, str(tmp_path), opt, 28, gx, intrinsics)
         tally[status] = tally.get(status, 0) + 1
-        assert status in ("ok", "unknown-op", "unsupported"), f"case {seed}: {status}: {info}"
+        assert status in ("ok", "unknown-op", "unsupported", "compiler-sunk-load"), f"case {seed}: {status}: {info}"
     assert tally.get("ok", 0) >= 6, tally  # (the rest: kernels in which the compiler used an instruction the interpreter does not know)
 
 

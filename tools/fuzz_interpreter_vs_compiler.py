@@ -9,7 +9,8 @@ programs: each case generates one HIP kernel out of language-defined building bl
     popcount / clz / ctz / bit reverse / byte swap, conversions,
   * wavefront crossings (__shfl, __shfl_xor, __shfl_up, __shfl_down with widths, __ballot, __any / __all),
   * LDS exchanges through __syncthreads with 4-, 8- and 16-byte accesses at permuted addresses,
-  * divergent if / else regions and data-dependent loops with early exits,
+  * divergent if / else regions and data-dependent loops with early exits; ballots and votes INSIDE divergent regions (only the
+    lanes that took the branch take part); wave-uniform loops that run until no lane of the wavefront has work left,
   * global loads of 4, 8 and 16 bytes,
   * with --intrinsics, the gfx950 builtins the product's kernels lean on (perm, alignbit, alignbyte, ubfe / sbfe, mbcnt, ds_bpermute,
     ds_permute, readlane, readfirstlane), whose host meaning is written here from the ISA manual's pseudo-code --
@@ -17,7 +18,8 @@ programs: each case generates one HIP kernel out of language-defined building bl
 compiles it TWICE: by hipcc for gfx950 (executed by the interpreter, with its hazard and s_waitcnt checkers on -- compiler output
 must never trip them) and, restated over arrays of all work-items, by clang++ for the host (executed natively).  The two results
 must be the same words.  Kernels in which the compiler used an instruction the interpreter does not know are counted and named,
-not failed.
+not failed; a wrong answer is first put to tools/audit_machine_sink.py (this image's LLVM can sink an LDS load past a barrier: such
+a case is the compiler's race, reported as "compiler-sunk-load").
 
     python3 tools/fuzz_interpreter_vs_compiler.py --seed 1 --cases 100 [--opt O1|O2|O3] [--keep DIR]
 """
@@ -36,6 +38,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 HIPCC = "/opt/rocm/bin/hipcc"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 BLOCK, GRID = 256, 2
@@ -172,6 +175,17 @@ class Gen:
                 return ("lds64", self.new(True), src, mul_w, add_w, mul_r, add_r)
             srcs = [r.choice(self.v32) for _ in range(4)]
             return ("lds128", self.new(False), srcs, mul_w, add_w, mul_r, add_r)
+        if k < 0.905:
+            # a ballot / vote INSIDE a divergent region: only the lanes that took the branch take part
+            cond = f"({self.x32()} {r.choice(['&', '^', '+'])} {self.x32()}) {r.choice(['& 1u', '& 4u', '> 0x7fffffffu', '% 3u == 1u'])}"
+            src = r.choice(self.v32)
+            if r.random() < 0.6:
+                return ("ifballot", self.new(True), cond, src, r.randrange(32))
+            return ("ifvote", self.new(False), cond, src, r.choice(["any", "all"]), r.getrandbits(32) >> r.randrange(1, 8))
+        if k < 0.92:
+            # a wave-uniform loop: every lane iterates until no lane of the wavefront has work left
+            src = r.choice(self.v32)
+            return ("waveloop", self.new(False), src, r.choice([1, 2, 3, 5]), r.choice([0xff, 0xfff, 0xffff]))
         if k < 0.95:
             cond = f"({self.x32()} {r.choice(['&', '^', '+'])} {self.x32()}) {r.choice(['& 1u', '& 4u', '> 0x7fffffffu', '< 0x40000000u', '% 3u == 1u'])}"
             then = [self.assign_existing() for _ in range(r.randrange(1, 4))]
@@ -260,6 +274,12 @@ def device_source(g: Gen) -> str:
             o.append(f"{pad}l128[(t * {mw}u + {aw}u) & 255u] = make_uint4({', '.join(srcs)}); __syncthreads();")
             o.append(f"{pad}const uint4 {name}_q = l128[(t * {mr}u + {ar}u) & 255u]; __syncthreads();")
             o.append(f"{pad}uint32_t {name} = {name}_q.x ^ ({name}_q.y << 1) ^ ({name}_q.z >> 1) ^ ({name}_q.w * 3u);")
+        elif k == "ifballot":
+            o.append(f"{pad}uint64_t {s[1]} = 0; if ({_fmt(s[2], False)}) {s[1]} = __ballot(({s[3]} >> {s[4]}u) & 1u);")
+        elif k == "ifvote":
+            o.append(f"{pad}uint32_t {s[1]} = 7u; if ({_fmt(s[2], False)}) {s[1]} = (uint32_t) __{s[4]}({s[3]} > {s[5]:#x}u);")
+        elif k == "waveloop":
+            o.append(f"{pad}uint32_t {s[1]} = 0; for (uint32_t rest = {s[2]} & {s[4]:#x}u; __any(rest != 0u); rest >>= {s[3]}u) {s[1]} += (rest & 1u) + 1u;")
         elif k == "if":
             o.append(f"{pad}if ({_fmt(s[1], False)}) {{")
             for x in s[2]:
@@ -370,6 +390,21 @@ def host_source(g: Gen) -> str:
             o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) { uint64_t m = 0;")
             o.append(f"        for (uint32_t l = 0; l < 64; ++l) m |= (uint64_t) (({s[2]}[w0 + l] >> {s[3]}u) & 1u) << l;")
             o.append(f"        for (uint32_t l = 0; l < 64; ++l) {s[1]}[w0 + l] = m; }}")
+        elif k == "ifballot":
+            o.append(f"    std::vector<uint64_t> {s[1]}(N, 0);")
+            o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) { uint64_t m = 0;")
+            o.append(f"        for (uint32_t l = 0; l < 64; ++l) {{ const uint32_t i = w0 + l; if ({_fmt(s[2], True)}) m |= (uint64_t) (({s[3]}[i] >> {s[4]}u) & 1u) << l; }}")
+            o.append(f"        for (uint32_t l = 0; l < 64; ++l) {{ const uint32_t i = w0 + l; if ({_fmt(s[2], True)}) {s[1]}[i] = m; }} }}")
+        elif k == "ifvote":
+            o.append(f"    std::vector<uint32_t> {s[1]}(N, 7u);")
+            o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) { uint32_t n = 0, in = 0;")
+            o.append(f"        for (uint32_t l = 0; l < 64; ++l) {{ const uint32_t i = w0 + l; if ({_fmt(s[2], True)}) {{ ++in; n += {s[3]}[i] > {s[5]:#x}u; }} }}")
+            o.append(f"        for (uint32_t l = 0; l < 64; ++l) {{ const uint32_t i = w0 + l; if ({_fmt(s[2], True)}) {s[1]}[i] = {'n != 0' if s[4] == 'any' else 'n == in'}; }} }}")
+        elif k == "waveloop":
+            o.append(f"    std::vector<uint32_t> {s[1]}(N, 0);")
+            o.append(f"    for (uint32_t w0 = 0; w0 < N; w0 += 64) {{ uint32_t rest[64]; for (uint32_t l = 0; l < 64; ++l) rest[l] = {s[2]}[w0 + l] & {s[4]:#x}u;")
+            o.append("        for (;;) { bool any = false; for (uint32_t l = 0; l < 64; ++l) any |= rest[l] != 0u; if (!any) break;")
+            o.append(f"            for (uint32_t l = 0; l < 64; ++l) {{ {s[1]}[w0 + l] += (rest[l] & 1u) + 1u; rest[l] >>= {s[3]}u; }} }} }}")
         elif k == "vote":
             o.append(f"    std::vector<uint32_t> {s[1]}(N);")
             o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) { uint32_t n = 0;")
@@ -441,6 +476,11 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
         return "interpreter-error", f"{type(e).__name__}: {e}"
     if np.array_equal(got, want):
         return "ok", {x.op for x in k.code.values()}
+    # a wrong answer that is the COMPILER's: this image's LLVM can sink an LDS load past __syncthreads() (tools/audit_machine_sink.py)
+    import audit_machine_sink
+    sunk = [b for _, _, _, b in audit_machine_sink.audit(dpath, [f"-{opt}"], workdir) if b]
+    if sunk:
+        return "compiler-sunk-load", f"{len(sunk)} load(s) moved across a barrier by machine-sink; the interpreter ran the race to a different answer"
     bad = np.flatnonzero(got != want)
     cols = sorted({int(b % stride) for b in bad})
     names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
@@ -455,6 +495,7 @@ def main():
     ap.add_argument("--opt", default="O3", choices=["O1", "O2", "O3", "Os"])
     ap.add_argument("--statements", type=int, default=28)
     ap.add_argument("--intrinsics", action="store_true", help="also draw from the gfx950 builtins the product's kernels use (host meaning: HOST_PRELUDE)")
+    ap.add_argument("--ops-out", default=None, help="append the opcodes executed in agreeing kernels to this file (one per line)")
     ap.add_argument("--keep", default=None, help="directory for the generated sources (default: a temporary one)")
     args = ap.parse_args()
     from tests import gfx950_exec as gx
@@ -479,6 +520,9 @@ def main():
             problems.append((seed, status, info))
             print(f"case {seed}: {status}: {info}", flush=True)
     print(f"seed {args.seed} -{args.opt}{' +intrinsics' if args.intrinsics else ''}: {dict(tally)} in {time.time() - t0:.0f} s; {len(ops_seen)} distinct opcodes executed in agreeing kernels")
+    if args.ops_out:
+        with open(args.ops_out, "a") as f:
+            f.write("".join(o + "\n" for o in sorted(ops_seen)))
     if unknown:
         print("  opcodes the interpreter does not know (kernels skipped):", dict(unknown.most_common()))
     if problems:
