@@ -723,6 +723,10 @@ def _dpp_source(w, i, src):
         frm = np.where(lane >= 1, lane - 1, -1)
     elif "wave_shl" in mods:
         frm = np.where(lane < 63, lane + 1, -1)
+    elif "wave_ror" in mods:
+        frm = (lane - 1) & 63
+    elif "wave_rol" in mods:
+        frm = (lane + 1) & 63
     else:
         raise Unsupported("DPP control: " + i.text)
     execm = mask_of(w.exec)
@@ -736,7 +740,7 @@ def _dpp_source(w, i, src):
     return val, write
 
 
-_DPP_KEYS = ("quad_perm", "row_shl", "row_shr", "row_ror", "row_bcast", "row_mirror", "row_half_mirror", "wave_shr", "wave_shl")
+_DPP_KEYS = ("quad_perm", "row_shl", "row_shr", "row_ror", "row_bcast", "row_mirror", "row_half_mirror", "wave_shr", "wave_shl", "wave_ror", "wave_rol")
 
 
 _SDWA_SEL = {"BYTE_0": (0, 8), "BYTE_1": (8, 8), "BYTE_2": (16, 8), "BYTE_3": (24, 8), "WORD_0": (0, 16), "WORD_1": (16, 16), "DWORD": (0, 32)}
@@ -996,6 +1000,25 @@ _reg("v_mad_i32_i24", 3, lambda a, b, c: ((_s24(a) * _s24(b)).astype(np.uint32) 
 def _(w, i):
     sh = np.broadcast_to(np.asarray(w.rv32(i.args[1]), dtype=np.uint32), (64,)).astype(np.int64) & np.int64(63)
     w.wv64(i.args[0], (np.broadcast_to(np.asarray(w.rv64(i.args[2]), dtype=np.uint64), (64,)).view(np.int64) >> sh).view(np.uint64))
+
+
+def _s_bfe_i32(a, b, c):
+    off, n = b & 31, (b >> 16) & 127
+    if n == 0:
+        return 0, False
+    f = (_sx(a, 32) >> off) & ((1 << n) - 1)      # (signed source: the shift is arithmetic, as in V_BFE_I32)
+    r = _sx(f, n) & M32 if n < 32 else f & M32
+    return r, r != 0
+
+
+_salu2("s_bfe_i32", 32, _s_bfe_i32)
+
+
+@op("s_bitset1_b32", "s_bitset0_b32")
+def _(w, i):
+    bit = 1 << (w.rs32(i.args[1]) & 31)
+    old = w.rs32(i.args[0])
+    w.ws32(i.args[0], (old | bit) if i.op == "s_bitset1_b32" else (old & ~bit & M32))
 
 
 @op("s_ashr_i64")

@@ -82,3 +82,47 @@ def test_reproducer_is_seen_by_the_audit_and_by_the_interpreter(tmp_path, sink):
         assert not right, "the load was sunk past the barrier, yet the skewed schedule did not expose the race"
     else:
         assert right  # (a compiler that no longer sinks the load)
+
+
+# ---- the second finding of the differential fuzz: SelectionDAG loses the high half of `uniform64 | ~zext(u32)` ---------------------
+# (AMD LLVM 22.0.0git of ROCm 7.2, hipcc -O1 .. -O3, gfx950 and gfx90a alike: when the ~zext value has a second use, the high half of
+# the OR -- all ones, whatever x is -- is taken from a register that was never loaded; GlobalISel compiles the same IR correctly.)
+# Nothing static can audit the product for a wrong instruction selection: that is what executing the BUILT code objects against the
+# oracle is for (tests/test_gfx950_exec.py, the -m gpu suite rehearsed on the interpreter).  Here the 6-line kernel is the control
+# that the interpreter tells the two builds apart.
+OR_NOT_ZEXT = r"""
+#include <hip/hip_runtime.h>
+#include <cstdint>
+extern "C" __global__ void k_or(const uint32_t *in, uint64_t *out, uint64_t x) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint64_t n = ~(uint64_t) in[i];     // high half: all ones
+    out[2 * i] = n;
+    out[2 * i + 1] = x | n;                   // high half: all ones, whatever x is
+}
+"""
+
+
+def test_selectiondag_or_of_not_zext_is_told_apart_from_globalisel(tmp_path):
+    from tests import gfx950_exec as gx
+
+    src = tmp_path / "or.hip"
+    src.write_text(OR_NOT_ZEXT)
+    x = np.random.default_rng(3).integers(0, 1 << 32, size=512, dtype=np.uint64).astype(np.uint32)
+    xarg = 0x0123456789ABCDEF
+    want = np.zeros(1024, dtype=np.uint64)
+    want[0::2] = ~x.astype(np.uint64)
+    want[1::2] = np.uint64(xarg) | ~x.astype(np.uint64)
+    right = {}
+    for name, flags in (("selectiondag", []), ("globalisel", ["-mllvm", "-global-isel", "-mllvm", "-global-isel-abort=2"])):
+        co = tmp_path / f"{name}.hsaco"
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "--genco", "--no-gpu-bundle-output", *flags, str(src), "-o", str(co)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        k = gx.Kernel(gx.CodeObject(str(co)), "k_or")
+        assert not k.missing, k.missing
+        got = np.zeros(1024, dtype=np.uint64)
+        gx.run_grid(k, 2, 256, 0, struct.pack("<QQQ", x.ctypes.data, got.ctypes.data, xarg), resident=2, quantum=400)
+        right[name] = bool(np.array_equal(got, want))
+        if not right[name]:
+            assert np.array_equal(got[0::2], want[0::2]) and np.array_equal(got[1::2] & np.uint64(0xFFFFFFFF), want[1::2] & np.uint64(0xFFFFFFFF)), "only the high half of the OR is lost"
+    assert right["globalisel"], right
+    # (selectiondag: wrong with this image's compiler, right with a fixed one -- either way the interpreter has said which)

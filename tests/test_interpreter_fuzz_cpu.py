@@ -18,16 +18,19 @@ def _tool():
     return m
 
 
-@pytest.mark.parametrize("intrinsics,opt,first", [(False, "O3", 9100000), (True, "O3", 9200000), (True, "O1", 9300000)])
-def test_random_kernels_agree_with_their_host_build(tmp_path, intrinsics, opt, first):
+@pytest.mark.parametrize("intrinsics,opt,first,model", [(False, "O3", 9100000, False), (True, "O3", 9200000, False), (True, "O1", 9300000, False),
+                                                      (True, "O3", 9400000, True)])
+def test_random_kernels_agree_with_their_host_build(tmp_path, intrinsics, opt, first, model):
+    """model=True: a third leg -- the same device text on the functional model (tests/wavesim) under a random fiber schedule"""
     from tests import gfx950_exec as gx
 
     tool = _tool()
     tally = {}
     for seed in range(first, first + 10):
-        status, info = tool.run_case(seed, str(tmp_path), opt, 28, gx, intrinsics)
+        status, info = tool.run_case(seed, str(tmp_path), opt, 28, gx, intrinsics, model)
         tally[status] = tally.get(status, 0) + 1
-        assert status in ("ok", "unknown-op", "unsupported", "compiler-sunk-load"), f"case {seed}: {status}: {info}"
+        # (the last two: the COMPILER's -- a load it sank past a barrier, its two instruction selectors disagreeing; tests/test_compiler_sink_audit.py)
+        assert status in ("ok", "unknown-op", "unsupported", "compiler-sunk-load", "codegen-disagreement"), f"case {seed}: {status}: {info}"
     assert tally.get("ok", 0) >= 6, tally  # (the rest: kernels in which the compiler used an instruction the interpreter does not know)
 
 

@@ -13,13 +13,16 @@ programs: each case generates one HIP kernel out of language-defined building bl
     lanes that took the branch take part); wave-uniform loops that run until no lane of the wavefront has work left,
   * global loads of 4, 8 and 16 bytes,
   * with --intrinsics, the gfx950 builtins the product's kernels lean on (perm, alignbit, alignbyte, ubfe / sbfe, mbcnt, ds_bpermute,
-    ds_permute, readlane, readfirstlane), whose host meaning is written here from the ISA manual's pseudo-code --
+    ds_permute, readlane, readfirstlane, and DPP moves -- quad_perm, row_shl / shr / ror, wave_shl / shr / rol / ror, row_mirror,
+    row_half_mirror, row_bcast:15 / 31, with row / bank masks and bound_ctrl, alone and where the compiler's DPP combiner folds them
+    into v_add_u32_dpp / v_and_b32_dpp / ...), whose host meaning is written here from the ISA manual's pseudo-code --
 
 compiles it TWICE: by hipcc for gfx950 (executed by the interpreter, with its hazard and s_waitcnt checkers on -- compiler output
 must never trip them) and, restated over arrays of all work-items, by clang++ for the host (executed natively).  The two results
 must be the same words.  Kernels in which the compiler used an instruction the interpreter does not know are counted and named,
 not failed; a wrong answer is first put to tools/audit_machine_sink.py (this image's LLVM can sink an LDS load past a barrier: such
-a case is the compiler's race, reported as "compiler-sunk-load").
+a case is the compiler's race, reported as "compiler-sunk-load") and then recompiled through the compiler's other instruction
+selector (GlobalISel): if that build runs to the host's answer it is reported as "codegen-disagreement", for a human to read.
 
     python3 tools/fuzz_interpreter_vs_compiler.py --seed 1 --cases 100 [--opt O1|O2|O3] [--keep DIR]
 """
@@ -50,9 +53,10 @@ class Gen:
     """One random program.  A statement is (kind, payload); expressions are format strings over {name} placeholders so that the
     device text (scalars) and the host text (arrays indexed by [i]) are the same characters."""
 
-    def __init__(self, rng: random.Random, intrinsics: bool = False):
+    def __init__(self, rng: random.Random, intrinsics: bool = False, model: bool = False):
         self.r = rng
         self.intrinsics = intrinsics
+        self.model = model      # also run on the functional model (tests/wavesim): leave out what it has no primitive for (ds_permute)
         self.v32 = ["a", "b", "c", "d"]
         self.v64 = ["p", "q"]
         self.n = 0
@@ -151,12 +155,20 @@ class Gen:
             src = r.choice(self.v32) if r.random() < 0.8 else r.choice(self.v64)
             wide = src in self.v64
             width = r.choice([64, 64, 64, 32, 16, 8])
-            how = r.choice(["xor", "up", "down", "idx", "idxv"] + (["bperm", "perm", "readlane", "first"] if self.intrinsics and not wide else []))
+            how = r.choice(["xor", "up", "down", "idx", "idxv"] + ((["bperm", "readlane", "first"] + ([] if self.model else ["perm"])) if self.intrinsics and not wide else []))
             if how in ("bperm", "perm", "readlane", "first"):
                 width = 64
             delta = r.randrange(1, width) if how != "idx" else r.randrange(0, width)
             sel = r.choice(self.v32)
             return ("cross", self.new(wide), wide, src, how, delta, width, sel)
+        if k < 0.70 and self.intrinsics:
+            # a DPP move, alone or where the compiler's DPP combiner can fold it into the consuming VALU instruction (v_add_u32_dpp ...)
+            src, other = r.choice(self.v32), r.choice(self.v32)
+            ctrl = r.choice([r.randrange(256), 0x100 + r.randrange(1, 16), 0x110 + r.randrange(1, 16), 0x120 + r.randrange(1, 16),
+                             0x130, 0x134, 0x138, 0x13c, 0x140, 0x141, 0x142, 0x143, 0x111, 0x112, 0x114, 0x118, 0x142, 0x143])
+            form = r.choice(["plain", "plain", "add", "and", "or", "xor", "masked"])
+            rm, bm, bc = (0xf, 0xf, r.random() < 0.5) if form != "masked" else (r.choice([0xf, 0xa, 0xc, 0x5, 0x8]), r.choice([0xf, 0xf, 0x3, 0xe]), r.random() < 0.5)
+            return ("dpp", self.new(False), src, other, ctrl, rm, bm, bc, form)
         if k < 0.74:
             src = r.choice(self.v32)
             return ("ballot", self.new(True), src, r.randrange(32))
@@ -175,6 +187,8 @@ class Gen:
                 return ("lds64", self.new(True), src, mul_w, add_w, mul_r, add_r)
             srcs = [r.choice(self.v32) for _ in range(4)]
             return ("lds128", self.new(False), srcs, mul_w, add_w, mul_r, add_r)
+        if k < 0.905 and self.model:
+            return self.plain()  # (the model refuses wave operations that only part of a wavefront reaches -- by design, loudly)
         if k < 0.905:
             # a ballot / vote INSIDE a divergent region: only the lanes that took the branch take part
             cond = f"({self.x32()} {r.choice(['&', '^', '+'])} {self.x32()}) {r.choice(['& 1u', '& 4u', '> 0x7fffffffu', '% 3u == 1u'])}"
@@ -218,9 +232,40 @@ static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint
 static inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t off, uint32_t n) { off &= 31u; n &= 31u; return n ? (v >> off) & ((1u << n) - 1u) : 0u; }
 static inline int32_t __builtin_amdgcn_sbfe(int32_t v, uint32_t off, uint32_t n) { off &= 31u; n &= 31u; if (!n) return 0;
     const uint32_t f = (uint32_t) (v >> off) & ((1u << n) - 1u);  /* arithmetic shift: a field past bit 31 is filled with the sign */ return (f >> (n - 1u)) & 1u ? (int32_t) (f | ~((1u << n) - 1u)) : (int32_t) f; }
+/* V_MOV_B32_DPP with every lane active (the tool uses it at the top level only): the ISA manual's DPP_CTRL table */
+static inline uint32_t dpp_host(uint32_t old, const uint32_t *src, uint32_t l, uint32_t ctrl, uint32_t rm, uint32_t bm, bool bc) {
+    const uint32_t row = l >> 4, r = l & 15u; int from = -1;
+    if (!((rm >> row) & 1u) || !((bm >> (r >> 2)) & 1u)) return old;
+    if (ctrl <= 0xffu) from = (int) ((l & ~3u) | ((ctrl >> (2u * (l & 3u))) & 3u));
+    else if (ctrl >= 0x101u && ctrl <= 0x10fu) { const uint32_t s = r + (ctrl - 0x100u); if (s < 16u) from = (int) (row * 16u + s); }
+    else if (ctrl >= 0x111u && ctrl <= 0x11fu) { const int s = (int) r - (int) (ctrl - 0x110u); if (s >= 0) from = (int) (row * 16u) + s; }
+    else if (ctrl >= 0x121u && ctrl <= 0x12fu) from = (int) (row * 16u + ((r - (ctrl - 0x120u)) & 15u));
+    else if (ctrl == 0x130u) { if (l + 1u < 64u) from = (int) l + 1; }
+    else if (ctrl == 0x134u) from = (int) ((l + 1u) & 63u);
+    else if (ctrl == 0x138u) { if (l >= 1u) from = (int) l - 1; }
+    else if (ctrl == 0x13cu) from = (int) ((l - 1u) & 63u);
+    else if (ctrl == 0x140u) from = (int) (row * 16u + (15u - r));
+    else if (ctrl == 0x141u) from = (int) (row * 16u + ((r & 8u) | (7u - (r & 7u))));
+    else if (ctrl == 0x142u) { if (row > 0u) from = (int) ((row - 1u) * 16u + 15u); }
+    else if (ctrl == 0x143u) { if (row >= 2u) from = 31; }
+    return from < 0 ? (bc ? 0u : old) : src[from];
+}
 #define __builtin_amdgcn_mbcnt_lo(m, add) ((uint32_t) __builtin_popcount((m) & (lane >= 32u ? 0xffffffffu : (1u << lane) - 1u)) + (add))
 #define __builtin_amdgcn_mbcnt_hi(m, add) ((uint32_t) __builtin_popcount((m) & (lane <= 32u ? 0u : (1u << (lane - 32u)) - 1u)) + (add))
 """
+
+
+def _dpp_text(s, host: bool) -> str:
+    """the DPP statement's right-hand side; on the host the builtin is dpp_host(old, source array of the wavefront, lane, ...)"""
+    _, name, src, other, ctrl, rm, bm, bc, form = s
+    ident = {"plain": None, "masked": None, "add": "0", "or": "0", "xor": "0", "and": "-1"}[form]
+    oth = f"{other}[i]" if host else other
+    old = oth if ident is None else ident
+    if host:
+        call = f"dpp_host((uint32_t) {old}, &{src}[w0], l, {ctrl:#x}u, {rm:#x}u, {bm:#x}u, {'true' if bc else 'false'})"
+    else:
+        call = f"(uint32_t) __builtin_amdgcn_update_dpp((int) {old}, (int) {src}, {ctrl:#x}, {rm:#x}, {bm:#x}, {'true' if bc else 'false'})"
+    return call if ident is None else f"{oth} {dict(add='+', xor='^', **{'or': '|', 'and': '&'})[form]} {call}"
 
 
 def _fmt(expr: str, host: bool) -> str:
@@ -260,6 +305,8 @@ def device_source(g: Gen) -> str:
                     "readlane": f"__builtin_amdgcn_readlane((int) {src}, {delta})",
                     "first": f"__builtin_amdgcn_readfirstlane((int) {src})"}[how]
             o.append(f"{pad}{ty} {name} = ({ty}) {call};")
+        elif k == "dpp":
+            o.append(f"{pad}uint32_t {s[1]} = {_dpp_text(s, False)};")
         elif k == "ballot":
             o.append(f"{pad}uint64_t {s[1]} = __ballot(({s[2]} >> {s[3]}u) & 1u);")
         elif k == "vote":
@@ -385,6 +432,11 @@ def host_source(g: Gen) -> str:
                 o.append(f"        from = seg + ((({sel}[w0 + l] >> 3) & 63u) & (W - 1u));")
             o.append(f"        {name}[w0 + l] = {src}[w0 + from];")
             o.append("    }")
+        elif k == "dpp":
+            _, name, src, other, ctrl, rm, bm, bc, form = s
+            o.append(f"    std::vector<uint32_t> {name}(N);")
+            o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) for (uint32_t l = 0; l < 64; ++l) { const uint32_t i = w0 + l;")
+            o.append(f"        {name}[i] = {_dpp_text(s, True)}; }}")
         elif k == "ballot":
             o.append(f"    std::vector<uint64_t> {s[1]}(N);")
             o.append("    for (uint32_t w0 = 0; w0 < N; w0 += 64) { uint64_t m = 0;")
@@ -436,6 +488,77 @@ def host_source(g: Gen) -> str:
     return "\n".join(o) + "\n", stride
 
 
+# The third leg (--model): the SAME device text, compiled for the host against tests/wavesim (the functional wave64 model the
+# sanitizer and large-array rehearsals of the product run on).  What the model's header lacks of this tool's vocabulary is defined
+# here out of its primitives (wave_exchange among the active lanes, wave_ballot).
+MODEL_PRELUDE = r"""
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+template<typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    const int self = wavesim_lane();
+    return wavesim_shfl_src(v, (self & (width - 1)) + static_cast<int>(d) >= width ? self : self + static_cast<int>(d));
+}
+static inline int __any(int p) { return __ballot(p != 0) != 0; }
+static inline int __all(int p) { return __ballot(p == 0) == 0; }
+#define __lane_u32 static_cast<uint32_t>(wavesim_lane())
+#define __builtin_amdgcn_alignbyte(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | static_cast<uint64_t>(lo)) >> (8u * ((s) & 3u)))
+static inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t off, uint32_t n) { off &= 31u; n &= 31u; return n ? (v >> off) & ((1u << n) - 1u) : 0u; }
+static inline int32_t __builtin_amdgcn_sbfe(int32_t v, uint32_t off, uint32_t n) { off &= 31u; n &= 31u; if (!n) return 0;
+    const uint32_t f = static_cast<uint32_t>(v >> off) & ((1u << n) - 1u); return (f >> (n - 1u)) & 1u ? static_cast<int32_t>(f | ~((1u << n) - 1u)) : static_cast<int32_t>(f); }
+#define __builtin_amdgcn_mbcnt_lo(m, add) (static_cast<uint32_t>(__builtin_popcount((m) & (__lane_u32 >= 32u ? 0xffffffffu : (1u << __lane_u32) - 1u))) + (add))
+#define __builtin_amdgcn_mbcnt_hi(m, add) (static_cast<uint32_t>(__builtin_popcount((m) & (__lane_u32 <= 32u ? 0u : (1u << (__lane_u32 - 32u)) - 1u))) + (add))
+#define __builtin_amdgcn_ds_bpermute(addr, v) static_cast<int>(wavesim_shfl_src(static_cast<uint32_t>(v), (static_cast<uint32_t>(addr) >> 2) & 63))
+#define __builtin_amdgcn_readfirstlane(v) static_cast<int>(wavesim_shfl_src(static_cast<uint32_t>(v), __builtin_ctzll(__ballot(true))))
+"""
+
+MODEL_MAIN = r"""
+int main(int argc, char **argv) {
+    if (argc != 5) return 2;
+    const size_t nin = strtoull(argv[3], nullptr, 0), nout = strtoull(argv[4], nullptr, 0);
+    std::vector<uint32_t> in(nin), out(nout, 0xDEADBEEFu);
+    FILE *f = fopen(argv[1], "rb"); if (!f || fread(in.data(), 4, nin, f) != nin) return 3; fclose(f);
+    hipLaunchKernelGGL(k_fuzz, dim3(GRID_), dim3(256), 0, nullptr, static_cast<const uint32_t *>(in.data()), out.data());
+    f = fopen(argv[2], "wb"); if (!f || fwrite(out.data(), 4, nout, f) != nout) return 4; fclose(f);
+    return 0;
+}
+"""
+
+
+def model_source(g) -> str:
+    dev = device_source(g).replace("#include <hip/hip_runtime.h>\n#include <cstdint>\n", "").replace('extern "C" __global__', "__global__")
+    return MODEL_PRELUDE + dev + MODEL_MAIN.replace("GRID_", str(GRID))
+
+
+_MODEL_OBJ = {}
+
+
+def run_model(g, seed: int, workdir: str, x: np.ndarray, stride: int):
+    """(status, output words): the case on tests/wavesim, under a seeded random fiber schedule"""
+    wdir = os.path.join(ROOT, "tests", "wavesim")
+    obj = _MODEL_OBJ.get(workdir)
+    if obj is None:
+        obj = os.path.join(workdir, "wavesim_model.o")
+        r = subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-Wno-unknown-attributes", "-I", wdir, "-c", os.path.join(wdir, "wavesim.cc"), "-o", obj], capture_output=True, text=True)
+        if r.returncode:
+            return "model-compile", r.stderr[-1500:]
+        _MODEL_OBJ[workdir] = obj
+    src, exe = os.path.join(workdir, f"case{seed}_model.cc"), os.path.join(workdir, f"case{seed}_model")
+    open(src, "w").write(model_source(g))
+    r = subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-Wno-unknown-attributes", "-Wno-shift-count-overflow", "-I", wdir, src, obj, "-ldl", "-o", exe], capture_output=True, text=True)
+    if r.returncode:
+        return "model-compile", r.stderr[-1500:]
+    fin, fout = os.path.join(workdir, f"case{seed}.in"), os.path.join(workdir, f"case{seed}.out")
+    x.tofile(fin)
+    r = subprocess.run([exe, fin, fout, str(x.size), str(N * stride)], capture_output=True, text=True, timeout=300, env={**os.environ, "WAVESIM_SCHEDULE": f"random:{seed % 1000}"})
+    if r.returncode:
+        return "model-run", f"rc {r.returncode}: {r.stderr[-800:]}"
+    return "ok", np.fromfile(fout, dtype=np.uint32)
+
+
 def inputs(rng: np.random.Generator) -> np.ndarray:
     x = rng.integers(0, 1 << 32, size=NIN * N, dtype=np.uint64).astype(np.uint32)
     # corner values sprinkled in: zeros, all-ones, sign bits, small numbers
@@ -445,8 +568,8 @@ def inputs(rng: np.random.Generator) -> np.ndarray:
     return x
 
 
-def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: bool = False):
-    g = Gen(random.Random(seed), intrinsics).build(nstmts)
+def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: bool = False, model: bool = False):
+    g = Gen(random.Random(seed), intrinsics, model).build(nstmts)
     dev = device_source(g)
     host, stride = host_source(g)
     dpath, hpath = os.path.join(workdir, f"case{seed}.hip"), os.path.join(workdir, f"case{seed}_host.cc")
@@ -463,6 +586,15 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     want = np.zeros(N * stride, dtype=np.uint32)
     L = C.CDLL(so)
     L.k_fuzz_host(C.c_void_p(x.ctypes.data), C.c_void_p(want.ctypes.data))
+    if model:
+        st, mgot = run_model(g, seed, workdir, x, stride)
+        if st != "ok":
+            return st, mgot
+        if not np.array_equal(mgot, want):
+            bad = np.flatnonzero(mgot != want)
+            names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
+            first = int(bad[0])
+            return "MODEL-MISMATCH", f"{bad.size} words differ; first: work-item {first // stride} {names[first % stride]} model {mgot[first]:#x} want {want[first]:#x}"
     k = gx.Kernel(gx.CodeObject(co), "k_fuzz")
     if k.missing:
         return "unknown-op", sorted(k.missing)
@@ -481,6 +613,22 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     sunk = [b for _, _, _, b in audit_machine_sink.audit(dpath, [f"-{opt}"], workdir) if b]
     if sunk:
         return "compiler-sunk-load", f"{len(sunk)} load(s) moved across a barrier by machine-sink; the interpreter ran the race to a different answer"
+    # ... or a disagreement between the compiler's two instruction selectors: the same source through GlobalISel.  If that build
+    # runs to the host's answer, SelectionDAG's code computes something else from the same IR (seen: `or i64 uniform, ~zext(i32)`
+    # with a second use of the ~zext gets the wrong high half -- tests/test_compiler_sink_audit.py holds the 12-line IR)
+    co2 = os.path.join(workdir, f"case{seed}_gisel.hsaco")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", f"-{opt}", "--genco", "--no-gpu-bundle-output", "-mllvm", "-global-isel", "-mllvm", "-global-isel-abort=2",
+                        dpath, "-o", co2], capture_output=True, text=True)
+    if r.returncode == 0:
+        k2 = gx.Kernel(gx.CodeObject(co2), "k_fuzz")
+        if not k2.missing:
+            got2 = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32)
+            try:
+                gx.run_grid(k2, GRID, BLOCK, 0, struct.pack("<QQ", x.ctypes.data, got2.ctypes.data), resident=2, quantum=400)
+                if np.array_equal(got2, want):
+                    return "codegen-disagreement", "the GlobalISel build of the same source runs to the host's answer, the SelectionDAG build does not"
+            except Exception:
+                pass
     bad = np.flatnonzero(got != want)
     cols = sorted({int(b % stride) for b in bad})
     names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
@@ -495,6 +643,7 @@ def main():
     ap.add_argument("--opt", default="O3", choices=["O1", "O2", "O3", "Os"])
     ap.add_argument("--statements", type=int, default=28)
     ap.add_argument("--intrinsics", action="store_true", help="also draw from the gfx950 builtins the product's kernels use (host meaning: HOST_PRELUDE)")
+    ap.add_argument("--model", action="store_true", help="a third leg: the same device text on the functional model (tests/wavesim) under a random fiber schedule")
     ap.add_argument("--ops-out", default=None, help="append the opcodes executed in agreeing kernels to this file (one per line)")
     ap.add_argument("--keep", default=None, help="directory for the generated sources (default: a temporary one)")
     args = ap.parse_args()
@@ -506,7 +655,7 @@ def main():
     t0 = time.time()
     for n in range(args.cases):
         seed = args.seed * 100000 + n
-        status, info = run_case(seed, work, args.opt, args.statements, gx, args.intrinsics)
+        status, info = run_case(seed, work, args.opt, args.statements, gx, args.intrinsics, args.model)
         tally[status] += 1
         if status == "ok":
             ops_seen |= info
@@ -519,7 +668,7 @@ def main():
         else:
             problems.append((seed, status, info))
             print(f"case {seed}: {status}: {info}", flush=True)
-    print(f"seed {args.seed} -{args.opt}{' +intrinsics' if args.intrinsics else ''}: {dict(tally)} in {time.time() - t0:.0f} s; {len(ops_seen)} distinct opcodes executed in agreeing kernels")
+    print(f"seed {args.seed} -{args.opt}{' +intrinsics' if args.intrinsics else ''}{' +model' if args.model else ''}: {dict(tally)} in {time.time() - t0:.0f} s; {len(ops_seen)} distinct opcodes executed in agreeing kernels")
     if args.ops_out:
         with open(args.ops_out, "a") as f:
             f.write("".join(o + "\n" for o in sorted(ops_seen)))
@@ -527,7 +676,7 @@ def main():
         print("  opcodes the interpreter does not know (kernels skipped):", dict(unknown.most_common()))
     if problems:
         print(f"  sources of the {len(problems)} problem cases kept in {work}")
-    return 1 if any(s in ("MISMATCH", "interpreter-error") for _, s, _ in problems) else 0
+    return 1 if any(s in ("MISMATCH", "MODEL-MISMATCH", "interpreter-error", "model-run", "model-compile") for _, s, _ in problems) else 0
 
 
 if __name__ == "__main__":
