@@ -1158,6 +1158,8 @@ def _quiet(fn):
 
 
 _reg("v_cvt_f32_u32", 1, lambda a: _fu(np.broadcast_to(a, (64,)).astype(np.float32)))
+for _k in range(4):  # (the divisor of LLVM's division expansion when it is known to fit a byte)
+    _reg(f"v_cvt_f32_ubyte{_k}", 1, (lambda k: lambda a: _fu(((np.broadcast_to(a, (64,)) >> np.uint32(8 * k)) & np.uint32(0xFF)).astype(np.float32)))(_k))
 _reg("v_rcp_iflag_f32 v_rcp_f32", 1, _quiet(lambda a: _fu(np.float32(1.0) / _f(a))))
 _reg("v_mul_f32", 2, _quiet(lambda a, b: _fu(_f(a) * _f(b))))
 _reg("v_trunc_f32", 1, lambda a: _fu(np.trunc(_f(a))))
@@ -1397,6 +1399,11 @@ OPS["global_atomic_or"] = _gatomic(lambda c, d: c | d)
 OPS["global_atomic_and"] = _gatomic(lambda c, d: c & d)
 OPS["global_atomic_swap"] = _gatomic(lambda c, d: d)
 OPS["global_atomic_umax"] = _gatomic(lambda c, d: max(c, d))
+OPS["global_atomic_umin"] = _gatomic(lambda c, d: min(c, d))
+OPS["global_atomic_xor"] = _gatomic(lambda c, d: c ^ d)
+OPS["global_atomic_sub"] = _gatomic(lambda c, d: c - d)
+OPS["global_atomic_smax"] = _gatomic(lambda c, d: c if _sx(c, 32) >= _sx(d, 32) else d)
+OPS["global_atomic_smin"] = _gatomic(lambda c, d: c if _sx(c, 32) <= _sx(d, 32) else d)
 OPS["global_atomic_add_x2"] = _gatomic(lambda c, d: c + d, 2)
 OPS["global_atomic_swap_x2"] = _gatomic(lambda c, d: d, 2)
 
