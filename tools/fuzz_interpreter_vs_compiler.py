@@ -11,7 +11,8 @@ programs: each case generates one HIP kernel out of language-defined building bl
   * LDS exchanges through __syncthreads with 4-, 8- and 16-byte accesses at permuted addresses,
   * divergent if / else regions and data-dependent loops with early exits; ballots and votes INSIDE divergent regions (only the
     lanes that took the branch take part); wave-uniform loops that run until no lane of the wavefront has work left,
-  * global loads of 4, 8 and 16 bytes,
+  * global loads of 4, 8 and 16 bytes; global atomics (add / or / and / xor / max / min) on a small table, results unused -- what
+    LLVM's atomic optimizer turns into a wave reduction and one atomic per wavefront,
   * with --intrinsics, the gfx950 builtins the product's kernels lean on (perm, alignbit, alignbyte, ubfe / sbfe, mbcnt, ds_bpermute,
     ds_permute, readlane, readfirstlane, and DPP moves -- quad_perm, row_shl / shr / ror, wave_shl / shr / rol / ror, row_mirror,
     row_half_mirror, row_bcast:15 / 31, with row / bank masks and bound_ctrl, alone and where the compiler's DPP combiner folds them
@@ -44,6 +45,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 HIPCC = "/opt/rocm/bin/hipcc"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+ATOMIC_BASE = {"add": 0, "or": 16, "max": 32, "min": 48, "and": 64, "xor": 80}   # 16 slots per operation in the `table` argument
+TABLE_WORDS = 96
 BLOCK, GRID = 256, 2
 N = BLOCK * GRID
 NIN = 6  # input planes of N words
@@ -96,6 +99,8 @@ class Gen:
             f"({x} << {k}u) | ({x} >> {32 - k}u)", f"({x} << {k}u) | ({y} >> {32 - k}u)",
             f"(uint32_t) ((int32_t) {x} >> {k})", f"(uint32_t) ((int32_t) {x} >> ({y} & 31u))",
             f"({x} < {y}) ? {z} : {x}", f"((int32_t) {x} < (int32_t) {y}) ? {y} : {z}", f"({x} == {y}) ? {z} : {y}",
+            f"({x} <= {y}) ? {z} : {x}", f"((int32_t) {x} <= (int32_t) {y}) ? {y} : {z}", f"({x} != {y}) ? {z} : {y}",
+            f"((int32_t) {x} >= (int32_t) {y}) ? {x} : {z}", f"({x} >= {y}) ? {y} : {z}",
             f"({x} < {y} ? {x} : {y})", f"({x} > {y} ? {x} : {y})", f"((int32_t) {x} > (int32_t) {y} ? {x} : {y})",
             f"(uint32_t) __builtin_popcount({x})", f"(uint32_t) __builtin_clz({x} | 1u)", f"(uint32_t) __builtin_ctz({x} | 0x80000000u)",
             f"__builtin_bitreverse32({x})", f"__builtin_bswap32({x})",
@@ -127,6 +132,7 @@ class Gen:
             f"{x} + {y}", f"{x} - {y}", f"{x} ^ {y}", f"{x} & {y}", f"{x} | {y}", f"~{x}", f"{x} * {y}",
             f"{x} << ({s} & 63u)", f"{x} >> ({s} & 63u)", f"{x} << {k}u", f"{x} >> {k}u", f"({x} << {k}u) | ({x} >> {64 - k}u)",
             f"(uint64_t) ((int64_t) {x} >> {k})", f"({x} < {y}) ? {x} : {y}", f"((int64_t) {x} < (int64_t) {y}) ? {y} : {x}",
+            f"({x} <= {y}) ? {y} : {x}", f"((int64_t) {x} >= (int64_t) {y}) ? {y} : {x}", f"({x} != {y}) ? {x} : ~{y}", f"((int64_t) {x} <= (int64_t) {y}) ? {x} : {y}",
             f"(uint64_t) {s} * (uint64_t) {self.x32()}", f"{x} + (uint64_t) {s}", f"({x} << 32) | (uint64_t) {s}",
             f"(uint64_t) __builtin_popcountll({x})", f"(uint64_t) __builtin_clzll({x} | 1ull)", f"(uint64_t) __builtin_ctzll({x} | 0x8000000000000000ull)",
             f"(uint64_t) (int64_t) (int32_t) {s}", f"{x} * 0x9e3779b97f4a7c15ull + {y}", f"({x} == {y}) ? 1ull : ({x} ^ {y})",
@@ -175,6 +181,15 @@ class Gen:
         if k < 0.78:
             src = r.choice(self.v32)
             return ("vote", self.new(False), src, r.choice(["any", "all"]), r.getrandbits(32) >> r.randrange(20, 32))
+        if k < 0.80:
+            # atomics on a small table in global memory, results not used: the table's final content does not depend on the order
+            how = r.choice(["add", "add", "or", "max", "min", "and", "xor"])
+            return ("atomic", how, r.choice(self.v32), r.choice(self.v32), r.choice([1, 3, 7, 15]))
+        if k < 0.815:
+            # two LDS reads a fixed distance apart (ds_read2 / ds_read2st64 material)
+            src = r.choice(self.v64)
+            mul_w = r.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 33, 65, 127, 129, 255])
+            return ("ldspair", self.new(True), src, mul_w, r.randrange(256), r.choice([1, 2, 64, 65, 128]))
         if k < 0.88:
             kind = r.choice(["u32", "u32", "u64", "u128"])
             mul_w = r.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 33, 65, 127, 129, 255])
@@ -277,7 +292,7 @@ def _fmt(expr: str, host: bool) -> str:
 
 def device_source(g: Gen) -> str:
     o = ["#include <hip/hip_runtime.h>", "#include <cstdint>",
-         'extern "C" __global__ void __launch_bounds__(256) k_fuzz(const uint32_t *in, uint32_t *out) {',
+         'extern "C" __global__ void __launch_bounds__(256) k_fuzz(const uint32_t *in, uint32_t *out, uint32_t *table) {',
          "    __shared__ uint32_t l32[256]; __shared__ uint64_t l64[256]; __shared__ uint4 l128[256];",
          "    const uint32_t t = threadIdx.x, i = blockIdx.x * 256u + t;",
          f"    uint32_t a = in[i], b = in[i + {N}], c = in[2 * {N} + (i ^ 1u)];",
@@ -316,6 +331,14 @@ def device_source(g: Gen) -> str:
             arr, ty = ("l32", "uint32_t") if k == "lds32" else ("l64", "uint64_t")
             o.append(f"{pad}{arr}[(t * {mw}u + {aw}u) & 255u] = {src}; __syncthreads();")
             o.append(f"{pad}{ty} {name} = {arr}[(t * {mr}u + {ar}u) & 255u]; __syncthreads();")
+        elif k == "atomic":
+            _, how, idx, val, mask = s
+            fn = {"add": "atomicAdd", "or": "atomicOr", "max": "atomicMax", "min": "atomicMin", "and": "atomicAnd", "xor": "atomicXor"}[how]
+            o.append(f"{pad}{fn}(&table[{ATOMIC_BASE[how]} + (({idx} >> 5) & {mask}u)], {val});")
+        elif k == "ldspair":
+            _, name, src, mw, aw, dist = s
+            o.append(f"{pad}l64[(t * {mw}u + {aw}u) & 255u] = {src}; __syncthreads();")
+            o.append(f"{pad}uint64_t {name} = l64[t & 127u] - l64[(t & 127u) + {dist}u]; __syncthreads();")
         elif k == "lds128":
             _, name, srcs, mw, aw, mr, ar = s
             o.append(f"{pad}l128[(t * {mw}u + {aw}u) & 255u] = make_uint4({', '.join(srcs)}); __syncthreads();")
@@ -368,7 +391,7 @@ def host_source(g: Gen) -> str:
     lanes of each wavefront; an LDS exchange is a scatter then a gather per workgroup."""
     o = ["#include <cstdint>", "#include <vector>", f"static const uint32_t N = {N};",
          "struct u4 { uint32_t x, y, z, w; };", HOST_PRELUDE,
-         'extern "C" void k_fuzz_host(const uint32_t *in, uint32_t *out) {',
+         'extern "C" void k_fuzz_host(const uint32_t *in, uint32_t *out, uint32_t *table) {',
          "    std::vector<uint32_t> a(N), b(N), c(N), d(N); std::vector<uint64_t> p(N), q(N);",
          "    for (uint32_t i = 0; i < N; ++i) {",
          "        a[i] = in[i]; b[i] = in[i + N]; c[i] = in[2 * N + (i ^ 1u)]; d[i] = in[3 * N + i];",
@@ -469,6 +492,21 @@ def host_source(g: Gen) -> str:
             o.append(f"    for (uint32_t g0 = 0; g0 < N; g0 += 256) {{ {ty} lds[256];")
             o.append(f"        for (uint32_t t = 0; t < 256; ++t) lds[(t * {mw}u + {aw}u) & 255u] = {src}[g0 + t];")
             o.append(f"        for (uint32_t t = 0; t < 256; ++t) {name}[g0 + t] = lds[(t * {mr}u + {ar}u) & 255u]; }}")
+        elif k == "atomic":
+            _, how, idx, val, mask = s
+            opx = {"add": "+=", "or": "|=", "and": "&=", "xor": "^="}.get(how)
+            o.append("    for (uint32_t i = 0; i < N; ++i) {")
+            o.append(f"        uint32_t &slot = table[{ATOMIC_BASE[how]} + (({idx}[i] >> 5) & {mask}u)];")
+            if opx:
+                o.append(f"        slot {opx} {val}[i]; }}")
+            else:
+                o.append(f"        slot = {val}[i] {'>' if how == 'max' else '<'} slot ? {val}[i] : slot; }}")
+        elif k == "ldspair":
+            _, name, src, mw, aw, dist = s
+            o.append(f"    std::vector<uint64_t> {name}(N);")
+            o.append("    for (uint32_t g0 = 0; g0 < N; g0 += 256) { uint64_t lds[256];")
+            o.append(f"        for (uint32_t t = 0; t < 256; ++t) lds[(t * {mw}u + {aw}u) & 255u] = {src}[g0 + t];")
+            o.append(f"        for (uint32_t t = 0; t < 256; ++t) {name}[g0 + t] = lds[t & 127u] - lds[(t & 127u) + {dist}u]; }}")
         elif k == "lds128":
             _, name, srcs, mw, aw, mr, ar = s
             o.append(f"    std::vector<uint32_t> {name}(N);")
@@ -502,6 +540,10 @@ template<typename T> static inline T __shfl_down(T v, unsigned d, int width = 64
     const int self = wavesim_lane();
     return wavesim_shfl_src(v, (self & (width - 1)) + static_cast<int>(d) >= width ? self : self + static_cast<int>(d));
 }
+static inline uint32_t atomicMax(uint32_t *p, uint32_t v) { return __atomic_fetch_max(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicMin(uint32_t *p, uint32_t v) { return __atomic_fetch_min(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicAnd(uint32_t *p, uint32_t v) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicXor(uint32_t *p, uint32_t v) { return __atomic_fetch_xor(p, v, __ATOMIC_SEQ_CST); }
 static inline int __any(int p) { return __ballot(p != 0) != 0; }
 static inline int __all(int p) { return __ballot(p == 0) == 0; }
 #define __lane_u32 static_cast<uint32_t>(wavesim_lane())
@@ -519,10 +561,11 @@ MODEL_MAIN = r"""
 int main(int argc, char **argv) {
     if (argc != 5) return 2;
     const size_t nin = strtoull(argv[3], nullptr, 0), nout = strtoull(argv[4], nullptr, 0);
-    std::vector<uint32_t> in(nin), out(nout, 0xDEADBEEFu);
+    std::vector<uint32_t> in(nin), out(nout, 0xDEADBEEFu), table(TABLE_WORDS_, 0u);
+    for (int k = 0; k < 16; ++k) table[MIN_BASE_ + k] = table[AND_BASE_ + k] = 0xffffffffu;
     FILE *f = fopen(argv[1], "rb"); if (!f || fread(in.data(), 4, nin, f) != nin) return 3; fclose(f);
-    hipLaunchKernelGGL(k_fuzz, dim3(GRID_), dim3(256), 0, nullptr, static_cast<const uint32_t *>(in.data()), out.data());
-    f = fopen(argv[2], "wb"); if (!f || fwrite(out.data(), 4, nout, f) != nout) return 4; fclose(f);
+    hipLaunchKernelGGL(k_fuzz, dim3(GRID_), dim3(256), 0, nullptr, static_cast<const uint32_t *>(in.data()), out.data(), table.data());
+    f = fopen(argv[2], "wb"); if (!f || fwrite(out.data(), 4, nout, f) != nout || fwrite(table.data(), 4, table.size(), f) != table.size()) return 4; fclose(f);
     return 0;
 }
 """
@@ -530,7 +573,8 @@ int main(int argc, char **argv) {
 
 def model_source(g) -> str:
     dev = device_source(g).replace("#include <hip/hip_runtime.h>\n#include <cstdint>\n", "").replace('extern "C" __global__', "__global__")
-    return MODEL_PRELUDE + dev + MODEL_MAIN.replace("GRID_", str(GRID))
+    main = MODEL_MAIN.replace("GRID_", str(GRID)).replace("TABLE_WORDS_", str(TABLE_WORDS)).replace("MIN_BASE_", str(ATOMIC_BASE["min"])).replace("AND_BASE_", str(ATOMIC_BASE["and"]))
+    return MODEL_PRELUDE + dev + main
 
 
 _MODEL_OBJ = {}
@@ -559,6 +603,13 @@ def run_model(g, seed: int, workdir: str, x: np.ndarray, stride: int):
     return "ok", np.fromfile(fout, dtype=np.uint32)
 
 
+def fresh_table() -> np.ndarray:
+    t = np.zeros(TABLE_WORDS, dtype=np.uint32)
+    t[ATOMIC_BASE["min"]:ATOMIC_BASE["min"] + 16] = 0xFFFFFFFF
+    t[ATOMIC_BASE["and"]:ATOMIC_BASE["and"] + 16] = 0xFFFFFFFF
+    return t
+
+
 def inputs(rng: np.random.Generator) -> np.ndarray:
     x = rng.integers(0, 1 << 32, size=NIN * N, dtype=np.uint64).astype(np.uint32)
     # corner values sprinkled in: zeros, all-ones, sign bits, small numbers
@@ -585,7 +636,9 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     x = inputs(np.random.default_rng(seed))
     want = np.zeros(N * stride, dtype=np.uint32)
     L = C.CDLL(so)
-    L.k_fuzz_host(C.c_void_p(x.ctypes.data), C.c_void_p(want.ctypes.data))
+    want_t = fresh_table()
+    L.k_fuzz_host(C.c_void_p(x.ctypes.data), C.c_void_p(want.ctypes.data), C.c_void_p(want_t.ctypes.data))
+    want = np.concatenate([want, want_t])
     if model:
         st, mgot = run_model(g, seed, workdir, x, stride)
         if st != "ok":
@@ -594,14 +647,16 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
             bad = np.flatnonzero(mgot != want)
             names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
             first = int(bad[0])
-            return "MODEL-MISMATCH", f"{bad.size} words differ; first: work-item {first // stride} {names[first % stride]} model {mgot[first]:#x} want {want[first]:#x}"
+            where = f"work-item {first // stride} {names[first % stride]}" if first < N * stride else f"table[{first - N * stride}]"
+            return "MODEL-MISMATCH", f"{bad.size} words differ; first: {where} model {mgot[first]:#x} want {want[first]:#x}"
     k = gx.Kernel(gx.CodeObject(co), "k_fuzz")
     if k.missing:
         return "unknown-op", sorted(k.missing)
-    got = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32)
+    got, got_t = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32), fresh_table()
     lds = k.lds_bytes if hasattr(k, "lds_bytes") else 0
     try:
-        gx.run_grid(k, GRID, BLOCK, lds, struct.pack("<QQ", x.ctypes.data, got.ctypes.data), resident=2, quantum=400)
+        gx.run_grid(k, GRID, BLOCK, lds, struct.pack("<QQQ", x.ctypes.data, got.ctypes.data, got_t.ctypes.data), resident=2, quantum=400)
+        got = np.concatenate([got, got_t])
     except gx.Unsupported as e:
         return "unsupported", str(e)
     except Exception as e:  # a hazard / wait report on compiler output, or an interpreter fault
@@ -622,10 +677,10 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     if r.returncode == 0:
         k2 = gx.Kernel(gx.CodeObject(co2), "k_fuzz")
         if not k2.missing:
-            got2 = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32)
+            got2, got2_t = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32), fresh_table()
             try:
-                gx.run_grid(k2, GRID, BLOCK, 0, struct.pack("<QQ", x.ctypes.data, got2.ctypes.data), resident=2, quantum=400)
-                if np.array_equal(got2, want):
+                gx.run_grid(k2, GRID, BLOCK, 0, struct.pack("<QQQ", x.ctypes.data, got2.ctypes.data, got2_t.ctypes.data), resident=2, quantum=400)
+                if np.array_equal(np.concatenate([got2, got2_t]), want):
                     return "codegen-disagreement", "the GlobalISel build of the same source runs to the host's answer, the SelectionDAG build does not"
             except Exception:
                 pass
@@ -633,7 +688,8 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     cols = sorted({int(b % stride) for b in bad})
     names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
     first = int(bad[0])
-    return "MISMATCH", f"{bad.size} words differ; columns {[names[c] for c in cols][:8]}; first: work-item {first // stride} {names[first % stride]} got {got[first]:#x} want {want[first]:#x}"
+    where = f"work-item {first // stride} {names[first % stride]}" if first < N * stride else f"table[{first - N * stride}]"
+    return "MISMATCH", f"{bad.size} words differ; columns {[names[c] for c in cols][:8]}; first: {where} got {got[first]:#x} want {want[first]:#x}"
 
 
 def main():
