@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import random
 import re
 import struct
 import subprocess
@@ -1596,11 +1597,29 @@ class Kernel:
 
 
 def run_grid(kernel: Kernel, grid: int, block: int, dynamic_lds: int, explicit_args: bytes, resident: int = 8, quantum=4000,
-             max_instructions: int = 400_000_000, trace=None):
+             max_instructions: int = 400_000_000, trace=None, order: str = None):
     """Execute `grid` workgroups of `block` work-items.  At most `resident` workgroups are in flight at a time and are started in
     blockIdx order; their wavefronts are interleaved round-robin, `quantum` instructions at a time (and at every s_sleep /
     s_barrier), so spin loops make progress.  (A persistent compress grid with sixteen ticket classes must be resident in full --
-    the launcher sizes it that way; `resident` below the grid is for the non-persistent kernels and the single-class case.)"""
+    the launcher sizes it that way; `resident` below the grid is for the non-persistent kernels and the single-class case.)
+    `order` (default: the environment's GFX950_EXEC_ORDER, else "forward"): the order the workgroups in flight and the wavefronts of
+    a workgroup take their turns in -- "forward" (index order: a later wavefront sees what the earlier ones did in their turn),
+    "reverse", or "random:<seed>" (reshuffled every pass).  A race only shows when the schedule lets the loser run first: a load the
+    compiler sank past a barrier (tools/audit_machine_sink.py) is overtaken by LATER wavefronts' stores only under "reverse"."""
+    order = order or os.environ.get("GFX950_EXEC_ORDER", "forward")
+    order_rng = random.Random(int(order.split(":")[1])) if order.startswith("random:") else None
+    if order not in ("forward", "reverse") and order_rng is None:
+        raise ValueError(f"order {order!r}")
+
+    def turns(seq):
+        if order == "forward":
+            return list(seq)
+        if order == "reverse":
+            return list(seq)[::-1]
+        out = list(seq)
+        order_rng.shuffle(out)
+        return out
+
     if kernel.missing:
         raise Unsupported(f"{kernel.name}: no semantics for {kernel.missing}")
     meta, desc = kernel.meta, kernel.desc
@@ -1662,8 +1681,8 @@ def run_grid(kernel: Kernel, grid: int, block: int, dynamic_lds: int, explicit_a
             live.append(make_wg(next_wg))
             next_wg += 1
         progressed = False
-        for wg in list(live):
-            for w in wg.waves:
+        for wg in turns(live):
+            for w in turns(wg.waves):
                 if w.state == Wave.DONE or w.state == Wave.BARRIER:
                     continue
                 w.state = Wave.RUNNING

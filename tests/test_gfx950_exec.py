@@ -88,14 +88,17 @@ def test_f32_3d_unpaired_tiles(bridge):
     assert any(n.endswith("Lb1ELb0EEEvPKNS_7word_ofIT_E4typeENS_9grid_geomEPjPS5_PyS9_jS9_jS9_") for n in names), names
 
 
-@pytest.mark.parametrize("quantum,cus,resident", [(37, 8, 32), (700, 3, 3), (4000, 8, 32), (150, 2, 1)])
-def test_tickets_and_lookback_under_different_interleavings(bridge, quantum, cus, resident, monkeypatch):
+@pytest.mark.parametrize("quantum,cus,resident,order", [(37, 8, 32, "forward"), (700, 3, 3, "forward"), (4000, 8, 32, "forward"), (150, 2, 1, "forward"),
+                                                        (37, 8, 32, "reverse"), (901, 8, 32, "random:3"), (150, 2, 1, "reverse")])
+def test_tickets_and_lookback_under_different_interleavings(bridge, quantum, cus, resident, order, monkeypatch):
     """24 tiles over 16 (24) workgroups, all in flight (sixteen ticket classes: the launcher's grid is what is resident, and the classes rely
     on it), and over 6 / 4 workgroups of which only 3 / 1 are in flight at a time (one class = a single global order, which needs no
     co-residency at all).  The wavefronts in flight are interleaved `quantum` instructions at a time, so aggregates are published
-    and windows are read in very different orders from case to case."""
+    and windows are read in very different orders from case to case.  `order`: which workgroup / wavefront takes its turn first --
+    index order, reverse, reshuffled every pass (a race shows only when its loser runs first; the whole module also runs under
+    GFX950_EXEC_ORDER=reverse / random:<seed>, profiles/r06_code_object_rehearsal.txt)."""
     real = gx.run_grid
-    monkeypatch.setattr(gx, "run_grid", lambda *a, **k: real(*a, **{**k, "quantum": quantum, "resident": resident}))
+    monkeypatch.setattr(gx, "run_grid", lambda *a, **k: real(*a, **{**k, "quantum": quantum, "resident": resident, "order": order}))
     data = _mixed((32, 64, 96), np.float32, 51)  # 48 hypercubes = 24 tiles
     want = oracle.compress(data)
     with bridge:

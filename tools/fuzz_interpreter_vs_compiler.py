@@ -655,7 +655,9 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     got, got_t = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32), fresh_table()
     lds = k.lds_bytes if hasattr(k, "lds_bytes") else 0
     try:
-        gx.run_grid(k, GRID, BLOCK, lds, struct.pack("<QQQ", x.ctypes.data, got.ctypes.data, got_t.ctypes.data), resident=2, quantum=400)
+        # (the schedule varies with the case: index order, reverse, reshuffled every pass -- a race shows only when its loser runs first)
+        gx.run_grid(k, GRID, BLOCK, lds, struct.pack("<QQQ", x.ctypes.data, got.ctypes.data, got_t.ctypes.data), resident=2, quantum=(400, 60, 2500)[seed % 3],
+                    order=("forward", "reverse", f"random:{seed}")[(seed // 3) % 3])
         got = np.concatenate([got, got_t])
     except gx.Unsupported as e:
         return "unsupported", str(e)
