@@ -30,4 +30,8 @@ for u in kernels_f32 kernels_f64 capi; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/$name.so" "$out/obj_$name"/*.o
+# this image's compiler can sink an LDS load past __syncthreads() (tools/audit_machine_sink.py): no variant with such a load is built
+audit=$(python3 "$root/tools/audit_machine_sink.py" "$src/kernels_f32.hip" "$src/kernels_f64.hip" "$src/capi.hip" "$@") \
+  || { echo "$audit" | grep -B1 -A1 "left behind" >&2; echo "build_variant: $name: machine-sink moved a load across a barrier -- variant removed" >&2; rm -f "$out/$name.so"; exit 1; }
+echo "$audit" | tail -1
 echo "$out/$name.so"
