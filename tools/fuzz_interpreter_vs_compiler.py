@@ -46,7 +46,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HIPCC = "/opt/rocm/bin/hipcc"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 ATOMIC_BASE = {"add": 0, "or": 16, "max": 32, "min": 48, "and": 64, "xor": 80}   # 16 slots per operation in the `table` argument
-TABLE_WORDS = 96
+TABLE_WORDS = 100
+TICKET_SLOT, TILES = 96, 5   # the ticket loop: workgroups draw tile numbers from table[96] until they run out (the product's persistent-kernel shape)
 BLOCK, GRID = 256, 2
 N = BLOCK * GRID
 NIN = 6  # input planes of N words
@@ -228,6 +229,10 @@ class Gen:
 
     def build(self, nstmts: int):
         self.stmts = [self.statement() for _ in range(nstmts)]
+        r = self.r
+        # half of the programs end in a ticket loop: (multiplier, offset) of the LDS write and read permutations, a mixing constant
+        self.ticket = (r.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 33, 65, 127, 129, 255]), r.randrange(256), r.randrange(1, 256), r.randrange(256),
+                       r.getrandbits(32), r.choice([1, 2, 3])) if r.random() < 0.5 else None
         return self
 
 
@@ -369,6 +374,24 @@ def device_source(g: Gen) -> str:
 
     for s in g.stmts:
         emit(s, 1)
+    if g.ticket:
+        mw, aw, mr, ar, mix, reads = g.ticket
+        o += ["    for (;;) {   // tiles are handed out by an atomic counter; which workgroup gets which tile does not matter to the result",
+              f"        if (t == 0) l32[0] = atomicAdd(&table[{TICKET_SLOT}], 1u);",
+              "        __syncthreads();",
+              "        const uint32_t tile = l32[0];",
+              "        __syncthreads();",
+              f"        if (tile >= {TILES}u) break;",
+              f"        const uint32_t sv = in[(tile * 97u + t * 3u) % {NIN * N}u] ^ {mix:#x}u;",
+              f"        l32[(t * {mw}u + {aw}u) & 255u] = sv; __syncthreads();",
+              f"        uint32_t rv = l32[(t * {mr}u + {ar}u) & 255u];"]
+        if reads >= 2:
+            o.append(f"        rv += l32[(t + 1u) & 255u] >> 3;")
+        if reads >= 3:
+            o.append(f"        rv ^= l32[(t ^ 32u) & 255u] * 5u;")
+        o += ["        __syncthreads();",
+              f"        out[(uint64_t) {N}u * STRIDE_ + tile * 256u + t] = rv + tile;",
+              "    }"]
     o.append("    uint32_t h = 0x811c9dc5u; uint64_t hh = 0xcbf29ce484222325ull;")
     for idx, v in enumerate(g.v32):
         o.append(f"    h = (h ^ {v}) * 0x01000193u;")
@@ -383,7 +406,7 @@ def device_source(g: Gen) -> str:
     o.append(f"    out[(uint64_t) i * {stride} + {stride - 2}] = (uint32_t) hh;")
     o.append(f"    out[(uint64_t) i * {stride} + {stride - 1}] = (uint32_t) (hh >> 32);")
     o.append("}")
-    return "\n".join(o) + "\n"
+    return ("\n".join(o) + "\n").replace("STRIDE_", str(stride))
 
 
 def host_source(g: Gen) -> str:
@@ -522,6 +545,17 @@ def host_source(g: Gen) -> str:
     for idx, v in enumerate(g.v64):
         o.append(f"        hh = (hh ^ {v}[i]) * 0x100000001b3ull; r[{base + 2 * idx}] = (uint32_t) {v}[i]; r[{base + 2 * idx + 1}] = (uint32_t) ({v}[i] >> 32);")
     o.append(f"        r[{stride - 3}] = h; r[{stride - 2}] = (uint32_t) hh; r[{stride - 1}] = (uint32_t) (hh >> 32); }}")
+    if g.ticket:
+        mw, aw, mr, ar, mix, reads = g.ticket
+        o.append(f"    for (uint32_t tile = 0; tile < {TILES}u; ++tile) {{ uint32_t lds[256];")
+        o.append(f"        for (uint32_t t = 0; t < 256; ++t) lds[(t * {mw}u + {aw}u) & 255u] = in[(tile * 97u + t * 3u) % {NIN * N}u] ^ {mix:#x}u;")
+        o.append(f"        for (uint32_t t = 0; t < 256; ++t) {{ uint32_t rv = lds[(t * {mr}u + {ar}u) & 255u];")
+        if reads >= 2:
+            o.append("            rv += lds[(t + 1u) & 255u] >> 3;")
+        if reads >= 3:
+            o.append("            rv ^= lds[(t ^ 32u) & 255u] * 5u;")
+        o.append(f"            out[(uint64_t) N * {stride} + tile * 256u + t] = rv + tile; }} }}")
+        o.append(f"    table[{TICKET_SLOT}] += {TILES}u + {GRID}u;   // every workgroup draws one number too many")
     o.append("}")
     return "\n".join(o) + "\n", stride
 
@@ -559,10 +593,11 @@ static inline int32_t __builtin_amdgcn_sbfe(int32_t v, uint32_t off, uint32_t n)
 
 MODEL_MAIN = r"""
 int main(int argc, char **argv) {
-    if (argc != 5) return 2;
-    const size_t nin = strtoull(argv[3], nullptr, 0), nout = strtoull(argv[4], nullptr, 0);
+    if (argc != 6) return 2;
+    const size_t nin = strtoull(argv[3], nullptr, 0), nout = strtoull(argv[4], nullptr, 0), zero_from = strtoull(argv[5], nullptr, 0);
     std::vector<uint32_t> in(nin), out(nout, 0xDEADBEEFu), table(TABLE_WORDS_, 0u);
     for (int k = 0; k < 16; ++k) table[MIN_BASE_ + k] = table[AND_BASE_ + k] = 0xffffffffu;
+    for (size_t k = zero_from; k < nout; ++k) out[k] = 0;
     FILE *f = fopen(argv[1], "rb"); if (!f || fread(in.data(), 4, nin, f) != nin) return 3; fclose(f);
     hipLaunchKernelGGL(k_fuzz, dim3(GRID_), dim3(256), 0, nullptr, static_cast<const uint32_t *>(in.data()), out.data(), table.data());
     f = fopen(argv[2], "wb"); if (!f || fwrite(out.data(), 4, nout, f) != nout || fwrite(table.data(), 4, table.size(), f) != table.size()) return 4; fclose(f);
@@ -597,7 +632,7 @@ def run_model(g, seed: int, workdir: str, x: np.ndarray, stride: int):
         return "model-compile", r.stderr[-1500:]
     fin, fout = os.path.join(workdir, f"case{seed}.in"), os.path.join(workdir, f"case{seed}.out")
     x.tofile(fin)
-    r = subprocess.run([exe, fin, fout, str(x.size), str(N * stride)], capture_output=True, text=True, timeout=300, env={**os.environ, "WAVESIM_SCHEDULE": f"random:{seed % 1000}"})
+    r = subprocess.run([exe, fin, fout, str(x.size), str(N * stride + TILES * 256), str(N * stride + TILES * 256 if g.ticket else N * stride)], capture_output=True, text=True, timeout=300, env={**os.environ, "WAVESIM_SCHEDULE": f"random:{seed % 1000}"})
     if r.returncode:
         return "model-run", f"rc {r.returncode}: {r.stderr[-800:]}"
     return "ok", np.fromfile(fout, dtype=np.uint32)
@@ -634,7 +669,7 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     if r.returncode:
         return "host-compile", r.stderr[-1500:]
     x = inputs(np.random.default_rng(seed))
-    want = np.zeros(N * stride, dtype=np.uint32)
+    want = np.zeros(N * stride + TILES * 256, dtype=np.uint32)
     L = C.CDLL(so)
     want_t = fresh_table()
     L.k_fuzz_host(C.c_void_p(x.ctypes.data), C.c_void_p(want.ctypes.data), C.c_void_p(want_t.ctypes.data))
@@ -647,12 +682,14 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
             bad = np.flatnonzero(mgot != want)
             names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
             first = int(bad[0])
-            where = f"work-item {first // stride} {names[first % stride]}" if first < N * stride else f"table[{first - N * stride}]"
+            where = f"work-item {first // stride} {names[first % stride]}" if first < N * stride else f"tile word {first - N * stride}" if first < N * stride + TILES * 256 else f"table[{first - N * stride - TILES * 256}]"
             return "MODEL-MISMATCH", f"{bad.size} words differ; first: {where} model {mgot[first]:#x} want {want[first]:#x}"
     k = gx.Kernel(gx.CodeObject(co), "k_fuzz")
     if k.missing:
         return "unknown-op", sorted(k.missing)
-    got, got_t = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32), fresh_table()
+    got, got_t = np.full(N * stride + TILES * 256, 0xDEADBEEF, dtype=np.uint32), fresh_table()
+    if not g.ticket:
+        got[N * stride:] = 0
     lds = k.lds_bytes if hasattr(k, "lds_bytes") else 0
     try:
         # (the schedule varies with the case: index order, reverse, reshuffled every pass -- a race shows only when its loser runs first)
@@ -679,7 +716,9 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     if r.returncode == 0:
         k2 = gx.Kernel(gx.CodeObject(co2), "k_fuzz")
         if not k2.missing:
-            got2, got2_t = np.full(N * stride, 0xDEADBEEF, dtype=np.uint32), fresh_table()
+            got2, got2_t = np.full(N * stride + TILES * 256, 0xDEADBEEF, dtype=np.uint32), fresh_table()
+            if not g.ticket:
+                got2[N * stride:] = 0
             try:
                 gx.run_grid(k2, GRID, BLOCK, 0, struct.pack("<QQQ", x.ctypes.data, got2.ctypes.data, got2_t.ctypes.data), resident=2, quantum=400)
                 if np.array_equal(np.concatenate([got2, got2_t]), want):
@@ -690,7 +729,7 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     cols = sorted({int(b % stride) for b in bad})
     names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
     first = int(bad[0])
-    where = f"work-item {first // stride} {names[first % stride]}" if first < N * stride else f"table[{first - N * stride}]"
+    where = f"work-item {first // stride} {names[first % stride]}" if first < N * stride else f"tile word {first - N * stride}" if first < N * stride + TILES * 256 else f"table[{first - N * stride - TILES * 256}]"
     return "MISMATCH", f"{bad.size} words differ; columns {[names[c] for c in cols][:8]}; first: {where} got {got[first]:#x} want {want[first]:#x}"
 
 
