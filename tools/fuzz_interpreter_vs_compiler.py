@@ -638,6 +638,51 @@ def run_model(g, seed: int, workdir: str, x: np.ndarray, stride: int):
     return "ok", np.fromfile(fout, dtype=np.uint32)
 
 
+class Hardware:
+    """The same code object on a real gfx950 device (tests/test_zz_hip_fuzz_hardware.py, tools/gpu_batch.sh explain): loaded with the HIP
+    module API through ctypes, buffers from torch.  Raises RuntimeError on any plumbing failure -- the callers tell that apart from a
+    result that differs."""
+
+    def __init__(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU")
+        self.torch = torch
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipGetErrorString.restype = C.c_char_p
+        self.hip.hipModuleLoad.argtypes = [C.c_void_p, C.c_char_p]
+        self.hip.hipModuleGetFunction.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        self.hip.hipModuleLaunchKernel.argtypes = [C.c_void_p] + [C.c_uint] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.hip.hipModuleUnload.argtypes = [C.c_void_p]
+        torch.zeros(1, device="cuda")  # (the runtime and its primary context)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: HIP error {rc}: {self.hip.hipGetErrorString(rc).decode(errors='replace')}")
+
+    def run(self, co_path: str, x: np.ndarray, nout: int, zero_from: int):
+        """(output words incl. the tile region, table) after one launch of k_fuzz"""
+        torch, hip = self.torch, self.hip
+        d_in = torch.from_numpy(x.view(np.int32)).cuda()
+        out0 = np.full(nout, 0xDEADBEEF, dtype=np.uint32)
+        out0[zero_from:] = 0
+        d_out = torch.from_numpy(out0.view(np.int32)).cuda()
+        d_table = torch.from_numpy(fresh_table().view(np.int32)).cuda()
+        mod, fn = C.c_void_p(), C.c_void_p()
+        self._check(hip.hipModuleLoad(C.byref(mod), co_path.encode()), "hipModuleLoad")
+        try:
+            self._check(hip.hipModuleGetFunction(C.byref(fn), mod, b"k_fuzz"), "hipModuleGetFunction")
+            args = C.create_string_buffer(struct.pack("<QQQ", d_in.data_ptr(), d_out.data_ptr(), d_table.data_ptr()))
+            size = C.c_size_t(24)
+            extra = (C.c_void_p * 5)(1, C.cast(args, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)  # HIP_LAUNCH_PARAM_BUFFER_POINTER / _SIZE / _END
+            torch.cuda.synchronize()
+            self._check(hip.hipModuleLaunchKernel(fn, GRID, 1, 1, BLOCK, 1, 1, 0, None, None, extra), "hipModuleLaunchKernel")
+            self._check(hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        finally:
+            hip.hipModuleUnload(mod)
+        return d_out.cpu().numpy().view(np.uint32), d_table.cpu().numpy().view(np.uint32)
+
+
 def fresh_table() -> np.ndarray:
     t = np.zeros(TABLE_WORDS, dtype=np.uint32)
     t[ATOMIC_BASE["min"]:ATOMIC_BASE["min"] + 16] = 0xFFFFFFFF
@@ -654,7 +699,9 @@ def inputs(rng: np.random.Generator) -> np.ndarray:
     return x
 
 
-def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: bool = False, model: bool = False):
+def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: bool = False, model: bool = False, hardware=None):
+    """hardware: a Hardware() -- the code object also runs on the device; its words must be the INTERPRETER's (that is what the
+    interpreter claims to be), whatever the host says: "HARDWARE-MISMATCH" otherwise"""
     g = Gen(random.Random(seed), intrinsics, model).build(nstmts)
     dev = device_source(g)
     host, stride = host_source(g)
@@ -700,6 +747,15 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
         return "unsupported", str(e)
     except Exception as e:  # a hazard / wait report on compiler output, or an interpreter fault
         return "interpreter-error", f"{type(e).__name__}: {e}"
+    if hardware is not None:
+        h_out, h_table = hardware.run(co, x, N * stride + TILES * 256, N * stride + TILES * 256 if g.ticket else N * stride)
+        hgot = np.concatenate([h_out, h_table])
+        if not np.array_equal(hgot, got):
+            import audit_machine_sink
+            if any(b for _, _, _, b in audit_machine_sink.audit(dpath, [f"-{opt}"], workdir)):
+                return "compiler-sunk-load", "a load moved across a barrier: device and interpreter may each run the race their own way"
+            bad = np.flatnonzero(hgot != got)
+            return "HARDWARE-MISMATCH", f"{bad.size} words differ between the device and the interpreter; first at {int(bad[0])}: device {hgot[bad[0]]:#x} interpreter {got[bad[0]]:#x} host {want[bad[0]]:#x}"
     if np.array_equal(got, want):
         return "ok", {x.op for x in k.code.values()}
     # a wrong answer that is the COMPILER's: this image's LLVM can sink an LDS load past __syncthreads() (tools/audit_machine_sink.py)
@@ -741,18 +797,20 @@ def main():
     ap.add_argument("--statements", type=int, default=28)
     ap.add_argument("--intrinsics", action="store_true", help="also draw from the gfx950 builtins the product's kernels use (host meaning: HOST_PRELUDE)")
     ap.add_argument("--model", action="store_true", help="a third leg: the same device text on the functional model (tests/wavesim) under a random fiber schedule")
+    ap.add_argument("--hardware", action="store_true", help="a fourth leg on a GPU box: the code object on the device; its words must be the interpreter's")
     ap.add_argument("--ops-out", default=None, help="append the opcodes executed in agreeing kernels to this file (one per line)")
     ap.add_argument("--keep", default=None, help="directory for the generated sources (default: a temporary one)")
     args = ap.parse_args()
     from tests import gfx950_exec as gx
 
+    hardware = Hardware() if args.hardware else None
     work = args.keep or tempfile.mkdtemp(prefix="fuzz_ivc_")
     os.makedirs(work, exist_ok=True)
     tally, ops_seen, unknown, problems = collections.Counter(), set(), collections.Counter(), []
     t0 = time.time()
     for n in range(args.cases):
         seed = args.seed * 100000 + n
-        status, info = run_case(seed, work, args.opt, args.statements, gx, args.intrinsics, args.model)
+        status, info = run_case(seed, work, args.opt, args.statements, gx, args.intrinsics, args.model, hardware)
         tally[status] += 1
         if status == "ok":
             ops_seen |= info
@@ -765,7 +823,7 @@ def main():
         else:
             problems.append((seed, status, info))
             print(f"case {seed}: {status}: {info}", flush=True)
-    print(f"seed {args.seed} -{args.opt}{' +intrinsics' if args.intrinsics else ''}{' +model' if args.model else ''}: {dict(tally)} in {time.time() - t0:.0f} s; {len(ops_seen)} distinct opcodes executed in agreeing kernels")
+    print(f"seed {args.seed} -{args.opt}{' +intrinsics' if args.intrinsics else ''}{' +model' if args.model else ''}{' +hardware' if args.hardware else ''}: {dict(tally)} in {time.time() - t0:.0f} s; {len(ops_seen)} distinct opcodes executed in agreeing kernels")
     if args.ops_out:
         with open(args.ops_out, "a") as f:
             f.write("".join(o + "\n" for o in sorted(ops_seen)))
@@ -773,7 +831,7 @@ def main():
         print("  opcodes the interpreter does not know (kernels skipped):", dict(unknown.most_common()))
     if problems:
         print(f"  sources of the {len(problems)} problem cases kept in {work}")
-    return 1 if any(s in ("MISMATCH", "MODEL-MISMATCH", "interpreter-error", "model-run", "model-compile") for _, s, _ in problems) else 0
+    return 1 if any(s in ("MISMATCH", "MODEL-MISMATCH", "HARDWARE-MISMATCH", "interpreter-error", "model-run", "model-compile") for _, s, _ in problems) else 0
 
 
 if __name__ == "__main__":

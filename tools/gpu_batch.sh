@@ -99,6 +99,10 @@ explain)
   timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_3d_decode_256.txt --config 5 --f64-work-items 256
   timeout 600 bash tools/pmc.sh ${O}_rocprofv3_summary_f64_3d_decode_128.txt --config 5 --f64-work-items 128
   cp gpurun_out/traffic.json profiles/traffic.json 2>/dev/null
+  # the interpreter against the SILICON: the random kernels of tools/fuzz_interpreter_vs_compiler.py on the device, the interpreter and
+  # the host (the repository's offline evidence rests on the first two agreeing; tests/test_zz_hip_fuzz_hardware.py is the slice in -m gpu)
+  (timeout 900 python tools/fuzz_interpreter_vs_compiler.py --seed 500 --cases 200 --intrinsics --hardware 2>&1 | tail -12) > ${O}_interpreter_vs_silicon.txt
+  cat ${O}_interpreter_vs_silicon.txt
   ;;
 stress)
   S=${O}_two_process_stress.txt
