@@ -126,3 +126,39 @@ def test_selectiondag_or_of_not_zext_is_told_apart_from_globalisel(tmp_path):
             assert np.array_equal(got[0::2], want[0::2]) and np.array_equal(got[1::2] & np.uint64(0xFFFFFFFF), want[1::2] & np.uint64(0xFFFFFFFF)), "only the high half of the OR is lost"
     assert right["globalisel"], right
     # (selectiondag: wrong with this image's compiler, right with a fixed one -- either way the interpreter has said which)
+
+
+# ---- the third finding: a wrong V_BITOP3_B32 truth table when an inner bitwise value is reached twice from one root ----------------
+# (gfx950 only -- the instruction is new there -- and in BOTH instruction selectors, which share the matcher; tools/audit_bitop3.py.)
+# This one can be looked for in the product: its optimised IR must not contain the trigger shape.
+
+def _bitop3_tool():
+    spec = importlib.util.spec_from_file_location("audit_bitop3", os.path.join(ROOT, "tools", "audit_bitop3.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("unit", ["kernels_f32", "kernels_f64", "capi"])
+def test_no_bitwise_expression_of_the_product_has_the_bitop3_trigger_shape(tmp_path, unit):
+    tool = _bitop3_tool()
+    hits, nroots = tool.audit(os.path.join(ROOT, "ndzip_amd", "csrc", unit + ".hip"), tool.PRODUCT_FLAGS, str(tmp_path))
+    assert nroots >= 5 and not hits, hits[:5]
+
+
+def test_bitop3_reproducer_is_flagged_and_its_table_is_known(tmp_path):
+    tool = _bitop3_tool()
+    hits, nroots = tool.scan_ir(tool.REPRODUCER_IR)
+    assert nroots == 4 and [(h[1], h[2]) for h in hits] == [("%r", ["%t"])]
+    # the table by the instruction's definition: S0 = 0xf0, S1 = 0xcc, S2 = 0xaa pushed through the expression
+    A, b, X = 0xF0, 0xCC, 0xAA
+    t = A & b
+    assert ((t & X) | (t ^ b)) == tool.REPRODUCER_TABLE == 0x8C
+    for extra in ((), ("-global-isel",)):
+        got = tool.emitted_table(tool.REPRODUCER_IR, str(tmp_path), extra)
+        assert got in (0x8C, 0xAC, None), hex(got)  # (0xac: this image's compiler, both selectors; 0x8c / no fusion: a fixed one)
+    # a tree-shaped expression of the same size is fused correctly by this compiler: (A & X) | (b ^ X) has no shared inner value
+    tree = "define i32 @f(i32 %A, i32 %b, i32 %X) {\n  %u = and i32 %A, %X\n  %v = xor i32 %b, %X\n  %r = or i32 %u, %v\n  ret i32 %r\n}\n"
+    assert not tool.scan_ir(tree)[0]
+    got = tool.emitted_table(tree, str(tmp_path))
+    assert got in (None, (A & X) | (b ^ X)), hex(got)

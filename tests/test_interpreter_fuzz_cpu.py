@@ -30,7 +30,7 @@ def test_random_kernels_agree_with_their_host_build(tmp_path, intrinsics, opt, f
         status, info = tool.run_case(seed, str(tmp_path), opt, 28, gx, intrinsics, model)
         tally[status] = tally.get(status, 0) + 1
         # (the last two: the COMPILER's -- a load it sank past a barrier, its two instruction selectors disagreeing; tests/test_compiler_sink_audit.py)
-        assert status in ("ok", "unknown-op", "unsupported", "compiler-sunk-load", "codegen-disagreement"), f"case {seed}: {status}: {info}"
+        assert status in ("ok", "unknown-op", "unsupported", "compiler-sunk-load", "codegen-disagreement", "compiler-bitop3"), f"case {seed}: {status}: {info}"
     assert tally.get("ok", 0) >= 6, tally  # (the rest: kernels in which the compiler used an instruction the interpreter does not know)
 
 

@@ -41,5 +41,5 @@ def test_device_and_interpreter_agree_on_random_kernels(tmp_path, intrinsics, op
             raise
         tally[status] = tally.get(status, 0) + 1
         assert status != "HARDWARE-MISMATCH", f"case {seed}: the device and the interpreter differ: {info}"
-        assert status in ("ok", "unknown-op", "unsupported", "compiler-sunk-load", "codegen-disagreement"), f"case {seed}: {status}: {info}"
+        assert status in ("ok", "unknown-op", "unsupported", "compiler-sunk-load", "codegen-disagreement", "compiler-bitop3"), f"case {seed}: {status}: {info}"
     assert tally.get("ok", 0) >= 7, tally

@@ -34,4 +34,8 @@ wait
 audit=$(python3 "$root/tools/audit_machine_sink.py" "$src/kernels_f32.hip" "$src/kernels_f64.hip" "$src/capi.hip" "$@") \
   || { echo "$audit" | grep -B1 -A1 "left behind" >&2; echo "build_variant: $name: machine-sink moved a load across a barrier -- variant removed" >&2; rm -f "$out/$name.so"; exit 1; }
 echo "$audit" | tail -1
+# ... and fuse a bitwise expression with a shared inner value into a wrong v_bitop3 table (tools/audit_bitop3.py)
+audit=$(python3 "$root/tools/audit_bitop3.py" "$src/kernels_f32.hip" "$src/kernels_f64.hip" "$src/capi.hip" "$@") \
+  || { echo "$audit" | tail -8 >&2; echo "build_variant: $name: a bitwise expression has the shape this compiler fuses wrongly -- variant removed" >&2; rm -f "$out/$name.so"; exit 1; }
+echo "$audit" | tail -1
 echo "$out/$name.so"

@@ -23,7 +23,8 @@ must never trip them) and, restated over arrays of all work-items, by clang++ fo
 must be the same words.  Kernels in which the compiler used an instruction the interpreter does not know are counted and named,
 not failed; a wrong answer is first put to tools/audit_machine_sink.py (this image's LLVM can sink an LDS load past a barrier: such
 a case is the compiler's race, reported as "compiler-sunk-load") and then recompiled through the compiler's other instruction
-selector (GlobalISel): if that build runs to the host's answer it is reported as "codegen-disagreement", for a human to read.
+selector (GlobalISel): if that build runs to the host's answer it is reported as "codegen-disagreement", for a human to read;
+what is still wrong then is held against tools/audit_bitop3.py (the v_bitop3 truth-table defect both selectors share): "compiler-bitop3".
 
     python3 tools/fuzz_interpreter_vs_compiler.py --seed 1 --cases 100 [--opt O1|O2|O3] [--keep DIR]
 """
@@ -781,6 +782,12 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
                     return "codegen-disagreement", "the GlobalISel build of the same source runs to the host's answer, the SelectionDAG build does not"
             except Exception:
                 pass
+    # ... or the compiler's v_bitop3 formation (tools/audit_bitop3.py): both selectors share the matcher that gets the truth table wrong when
+    # an inner bitwise value is reached twice from one root -- if this case's IR has that shape, the wrong answer is put down to it
+    import audit_bitop3
+    hits, _ = audit_bitop3.audit(dpath, [f"-{opt}"], workdir)
+    if hits and audit_bitop3.emitted_table(audit_bitop3.REPRODUCER_IR, workdir) != audit_bitop3.REPRODUCER_TABLE:
+        return "compiler-bitop3", f"{len(hits)} bitwise expression(s) of the shape this compiler fuses into a wrong v_bitop3 table (e.g. {hits[0][1]} reaches {hits[0][2]} twice)"
     bad = np.flatnonzero(got != want)
     cols = sorted({int(b % stride) for b in bad})
     names = g.v32 + [f"{v}.{h}" for v in g.v64 for h in ("lo", "hi")] + ["h", "hh.lo", "hh.hi"]
