@@ -47,3 +47,62 @@ def test_signed_bitfield_extract_past_bit_31_is_arithmetic():
     assert (got == 1).all()
     got = gx._bfe_i32(np.full(64, 0x00000005, dtype=np.uint32), np.uint32(0), np.uint32(3))
     assert (got == 0xFFFFFFFD).all()
+
+
+def test_hardware_leg_plumbing_against_a_mock_runtime(tmp_path):
+    """tools/fuzz_interpreter_vs_compiler.py --hardware (tests/test_zz_hip_fuzz_hardware.py on a GPU box) has never met a device: here its
+    Python side -- buffers, the HIP_LAUNCH_PARAM `extra` array, the read-back, the comparison -- runs against a stand-in for libamdhip64
+    whose hipModuleLaunchKernel unpacks the arguments as the runtime would and executes the code object on the interpreter."""
+    import ctypes as C
+
+    from tests import gfx950_exec as gx
+
+    tool = _tool()
+
+    class Tensor:
+        def __init__(self, a):
+            self.a = a.copy()
+
+        def cuda(self):
+            return self
+
+        def cpu(self):
+            return self
+
+        def data_ptr(self):
+            return self.a.ctypes.data
+
+        def numpy(self):
+            return self.a
+
+    class Torch:
+        class cuda:
+            synchronize = staticmethod(lambda: None)
+
+        from_numpy = staticmethod(Tensor)
+
+    class Hip:
+        def hipModuleLoad(self, ref, path):
+            self.path = path.decode()
+            return 0
+
+        def hipModuleGetFunction(self, ref, mod, name):
+            self.name = name.decode()
+            return 0
+
+        def hipModuleLaunchKernel(self, fn, gx_, gy, gz, bx, by, bz, shmem, stream, params, extra):
+            assert params is None and (extra[0], extra[2], extra[4]) == (1, 2, 3)  # HIP_LAUNCH_PARAM_BUFFER_POINTER / _SIZE / _END
+            size = C.cast(extra[3], C.POINTER(C.c_size_t))[0]
+            gx.run_grid(gx.Kernel(gx.CodeObject(self.path), self.name), gx_, bx, shmem, C.string_at(extra[1], size), resident=2, quantum=400)
+            return 0
+
+        hipDeviceSynchronize = staticmethod(lambda: 0)
+        hipModuleUnload = staticmethod(lambda mod: 0)
+
+    hw = tool.Hardware.__new__(tool.Hardware)
+    hw.torch, hw.hip = Torch, Hip()
+    seen = set()
+    for seed in (9500000, 9500001, 9500003):  # (one of them ends in a ticket loop: the tile region and the table travel too)
+        status, _ = tool.run_case(seed, str(tmp_path), "O3", 28, gx, True, False, hw)
+        seen.add(status)
+    assert seen == {"ok"}, seen

@@ -2,12 +2,15 @@
 the interpreter against the COMPILER (tests/test_interpreter_fuzz_cpu.py: random HIP kernels, gfx950 code on the interpreter vs the
 host build); here, on a GPU box, the same random kernels' code objects run on the DEVICE as well, and the device's words must be the
 interpreter's -- every one, whatever the host build says (a disagreement of both with the host is the compiler's, see
-tests/test_compiler_sink_audit.py).
+docs/compiler_findings.md).
 
-hardware_only, and last in the session (tests/conftest.py): nothing rehearsed can be hidden by a surprise here.  A failure of the
-plumbing (HIP module API through ctypes, never run before a GPU was reachable) is a skip with its message, not a verdict."""
-import importlib.util
+hardware_only, and last in the session (tests/conftest.py): nothing rehearsed can be hidden by a surprise here.  The leg runs in a
+child process under a timeout: the HIP module API through ctypes has never run before a GPU was reachable, and a crash or a hang of
+that plumbing is a skip with its message, not a verdict -- a HARDWARE-MISMATCH the tool reports is."""
 import os
+import re
+import subprocess
+import sys
 
 import pytest
 
@@ -15,31 +18,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = [pytest.mark.gpu, pytest.mark.hardware_only]
 
 
-def _tool():
-    spec = importlib.util.spec_from_file_location("fuzz_ivc", os.path.join(ROOT, "tools", "fuzz_interpreter_vs_compiler.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
-    return m
-
-
-@pytest.mark.parametrize("intrinsics,opt,first", [(True, "O3", 9500000), (True, "O1", 9600000)])
-def test_device_and_interpreter_agree_on_random_kernels(tmp_path, intrinsics, opt, first):
-    from tests import gfx950_exec as gx
-
-    tool = _tool()
+@pytest.mark.parametrize("opt,seed", [("O3", 95), ("O1", 96)])
+def test_device_and_interpreter_agree_on_random_kernels(tmp_path, opt, seed):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_interpreter_vs_compiler.py"), "--seed", str(seed), "--cases", "12", "--opt", opt,
+           "--intrinsics", "--hardware", "--keep", str(tmp_path)]
     try:
-        hw = tool.Hardware()
-    except Exception as e:  # no device, no runtime library
-        pytest.skip(f"hardware leg not available: {e}")
-    tally = {}
-    for seed in range(first, first + 12):
-        try:
-            status, info = tool.run_case(seed, str(tmp_path), opt, 28, gx, intrinsics, False, hw)
-        except RuntimeError as e:
-            if "HIP error" in str(e) or "hipModule" in str(e):
-                pytest.skip(f"HIP module plumbing: {e}")
-            raise
-        tally[status] = tally.get(status, 0) + 1
-        assert status != "HARDWARE-MISMATCH", f"case {seed}: the device and the interpreter differ: {info}"
-        assert status in ("ok", "unknown-op", "unsupported", "compiler-sunk-load", "codegen-disagreement", "compiler-bitop3"), f"case {seed}: {status}: {info}"
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        pytest.skip("hardware leg: no answer within 600 s")
+    out = r.stdout + r.stderr
+    m = re.search(r"^seed \d+ .*?: (\{.*?\}) in", out, re.M)
+    if "HARDWARE-MISMATCH" in out:
+        pytest.fail("the device and the interpreter differ:\n" + "\n".join(l for l in out.splitlines() if "HARDWARE-MISMATCH" in l)[:3000])
+    if m is None:  # the tool did not get to its summary: the plumbing (HIP module API through ctypes), not a result
+        pytest.skip(f"hardware leg did not complete (rc {r.returncode}): {out[-1500:]}")
+    tally = eval(m.group(1), {"__builtins__": {}})
+    assert not any(k in tally for k in ("MISMATCH", "interpreter-error")), out[-3000:]
     assert tally.get("ok", 0) >= 7, tally

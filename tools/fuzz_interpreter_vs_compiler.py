@@ -649,13 +649,20 @@ class Hardware:
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU")
         self.torch = torch
-        self.hip = C.CDLL("libamdhip64.so")
+        torch.zeros(1, device="cuda")  # (the runtime and its primary context)
+        # the SAME runtime library torch has loaded (it ships its own copy: a second one in the process would not know torch's pointers)
+        path = "libamdhip64.so"
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        self.hip = C.CDLL(path)
         self.hip.hipGetErrorString.restype = C.c_char_p
         self.hip.hipModuleLoad.argtypes = [C.c_void_p, C.c_char_p]
         self.hip.hipModuleGetFunction.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
         self.hip.hipModuleLaunchKernel.argtypes = [C.c_void_p] + [C.c_uint] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]
         self.hip.hipModuleUnload.argtypes = [C.c_void_p]
-        torch.zeros(1, device="cuda")  # (the runtime and its primary context)
 
     def _check(self, rc, what):
         if rc != 0:
