@@ -1400,6 +1400,12 @@ OPS["global_atomic_or"] = _gatomic(lambda c, d: c | d)
 OPS["global_atomic_and"] = _gatomic(lambda c, d: c & d)
 OPS["global_atomic_swap"] = _gatomic(lambda c, d: d)
 OPS["global_atomic_umax"] = _gatomic(lambda c, d: max(c, d))
+@op("buffer_wbl2", "buffer_inv")
+def _(w, i):
+    """cache write-back / invalidate of release and acquire at agent scope: the interpreter's memory is one coherent array, nothing to do
+    (not among the product's instructions -- its look-back orders with sc1 accesses; here for tools/fuzz_interpreter_vs_compiler.py)"""
+
+
 OPS["global_atomic_umin"] = _gatomic(lambda c, d: min(c, d))
 OPS["global_atomic_xor"] = _gatomic(lambda c, d: c ^ d)
 OPS["global_atomic_sub"] = _gatomic(lambda c, d: c - d)

@@ -47,7 +47,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HIPCC = "/opt/rocm/bin/hipcc"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 ATOMIC_BASE = {"add": 0, "or": 16, "max": 32, "min": 48, "and": 64, "xor": 80}   # 16 slots per operation in the `table` argument
-TABLE_WORDS = 100
+TABLE_WORDS = 104
+PAIR_SLOT = 100                # (8-byte aligned: the "packed" chain's (sum, flag) pairs)
+FLAG_SLOT, SUM_SLOT = 97, 99   # the chain: workgroup b waits for workgroup b - 1's flag, adds its word to that one's sum, publishes both (look-back)
 TICKET_SLOT, TILES = 96, 5   # the ticket loop: workgroups draw tile numbers from table[96] until they run out (the product's persistent-kernel shape)
 BLOCK, GRID = 256, 2
 N = BLOCK * GRID
@@ -234,6 +236,9 @@ class Gen:
         # half of the programs end in a ticket loop: (multiplier, offset) of the LDS write and read permutations, a mixing constant
         self.ticket = (r.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 33, 65, 127, 129, 255]), r.randrange(256), r.randrange(1, 256), r.randrange(256),
                        r.getrandbits(32), r.choice([1, 2, 3])) if r.random() < 0.5 else None
+        # ... and a third in a chain across the workgroups: release / acquire at agent scope, a spin with s_sleep (the product's look-back)
+        # ("packed": flag and sum in ONE 8-byte relaxed atomic, the product's form; "fenced": two words, release / acquire)
+        self.chain = (r.getrandbits(32), r.choice(self.v32), r.choice(["fenced", "packed"])) if r.random() < 0.35 else None
         return self
 
 
@@ -375,6 +380,29 @@ def device_source(g: Gen) -> str:
 
     for s in g.stmts:
         emit(s, 1)
+    if g.chain and g.chain[2] == "packed":
+        mix, var, _ = g.chain
+        o += ["    if (t == 0) {   // workgroup b: wait for b - 1's (flag, sum) pair -- one 8-byte relaxed atomic --, add, publish its own",
+              f"        unsigned long long *pairs = (unsigned long long *) (table + {PAIR_SLOT});",
+              f"        const uint32_t mine = (in[blockIdx.x * 7u + 3u] ^ {mix:#x}u) + ({var} & 0u);",
+              "        unsigned long long seen = 1ull << 32;",
+              "        if (blockIdx.x > 0) {",
+              "            do { seen = __hip_atomic_load(&pairs[blockIdx.x - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(seen >> 32)) __builtin_amdgcn_s_sleep(1); } while (!(seen >> 32));",
+              "        }",
+              "        __hip_atomic_store(&pairs[blockIdx.x], (1ull << 32) | (uint32_t) ((uint32_t) seen + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);",
+              "    }"]
+    elif g.chain:
+        mix, var, _ = g.chain
+        o += ["    if (t == 0) {   // workgroup b: wait for b - 1, add, publish -- data first, then the flag with release",
+              f"        const uint32_t mine = (in[blockIdx.x * 7u + 3u] ^ {mix:#x}u) + ({var} & 0u);",
+              "        uint32_t before = 0;",
+              "        if (blockIdx.x > 0) {",
+              f"            while (__hip_atomic_load(&table[{FLAG_SLOT} + blockIdx.x - 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);",
+              f"            before = __hip_atomic_load(&table[{SUM_SLOT} + blockIdx.x - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);",
+              "        }",
+              f"        __hip_atomic_store(&table[{SUM_SLOT} + blockIdx.x], before + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);",
+              f"        __hip_atomic_store(&table[{FLAG_SLOT} + blockIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);",
+              "    }"]
     if g.ticket:
         mw, aw, mr, ar, mix, reads = g.ticket
         o += ["    for (;;) {   // tiles are handed out by an atomic counter; which workgroup gets which tile does not matter to the result",
@@ -546,6 +574,12 @@ def host_source(g: Gen) -> str:
     for idx, v in enumerate(g.v64):
         o.append(f"        hh = (hh ^ {v}[i]) * 0x100000001b3ull; r[{base + 2 * idx}] = (uint32_t) {v}[i]; r[{base + 2 * idx + 1}] = (uint32_t) ({v}[i] >> 32);")
     o.append(f"        r[{stride - 3}] = h; r[{stride - 2}] = (uint32_t) hh; r[{stride - 1}] = (uint32_t) (hh >> 32); }}")
+    if g.chain and g.chain[2] == "packed":
+        mix = g.chain[0]
+        o.append(f"    for (uint32_t b = 0, sum = 0; b < {GRID}u; ++b) {{ sum += in[b * 7u + 3u] ^ {mix:#x}u; table[{PAIR_SLOT} + 2u * b] = sum; table[{PAIR_SLOT} + 2u * b + 1u] = 1u; }}")
+    elif g.chain:
+        mix = g.chain[0]
+        o.append(f"    for (uint32_t b = 0, sum = 0; b < {GRID}u; ++b) {{ sum += in[b * 7u + 3u] ^ {mix:#x}u; table[{SUM_SLOT} + b] = sum; table[{FLAG_SLOT} + b] = 1u; }}")
     if g.ticket:
         mw, aw, mr, ar, mix, reads = g.ticket
         o.append(f"    for (uint32_t tile = 0; tile < {TILES}u; ++tile) {{ uint32_t lds[256];")
