@@ -997,6 +997,45 @@ _reg("v_mul_hi_u32_u24", 2, lambda a, b: (((a & np.uint32(0xFFFFFF)).astype(np.u
 _reg("v_mad_i32_i24", 3, lambda a, b, c: ((_s24(a) * _s24(b)).astype(np.uint32) + c))
 
 
+# 16-bit VALU (gfx9: the result's high 16 bits are written as zero -- the compiler drops zero-extensions on that account; the "legacy"
+# multiply-adds are the forms that do the same in VOP3)
+_H = np.uint32(0xFFFF)
+
+
+def _s16(x):
+    x = (np.broadcast_to(x, (64,)).astype(np.int64)) & 0xFFFF
+    return np.where(x & 0x8000, x - 0x10000, x)
+
+
+_reg("v_add_u16", 2, lambda a, b: (a + b) & _H)
+_reg("v_sub_u16", 2, lambda a, b: (a - b) & _H)
+_reg("v_subrev_u16", 2, lambda a, b: (b - a) & _H)
+_reg("v_mul_lo_u16", 2, lambda a, b: ((a & _H) * (b & _H)) & _H)
+_reg("v_max_u16", 2, lambda a, b: np.maximum(a & _H, b & _H))
+_reg("v_min_u16", 2, lambda a, b: np.minimum(a & _H, b & _H))
+_reg("v_max_i16", 2, lambda a, b: np.maximum(_s16(a), _s16(b)).astype(np.uint32) & _H)
+_reg("v_min_i16", 2, lambda a, b: np.minimum(_s16(a), _s16(b)).astype(np.uint32) & _H)
+_reg("v_lshlrev_b16", 2, lambda a, b: ((b & _H) << (a & np.uint32(15))) & _H)
+_reg("v_ashrrev_i16", 2, lambda a, b: (_s16(b) >> (np.broadcast_to(a, (64,)).astype(np.int64) & 15)).astype(np.uint32) & _H)
+_reg("v_mad_legacy_u16", 3, lambda a, b, c: ((a & _H) * (b & _H) + (c & _H)) & _H)
+_reg("v_mad_legacy_i16", 3, lambda a, b, c: (_s16(a) * _s16(b) + _s16(c)).astype(np.uint32) & _H)
+
+
+def _vcmp16(w, i):
+    m = re.match(r"v_cmp_(\w+?)_([iu])16", i.op)
+    c, sg = m.group(1), m.group(2)
+    a = np.broadcast_to(np.asarray(w.rv32(i.args[1]), dtype=np.uint32), (64,))
+    b = np.broadcast_to(np.asarray(w.rv32(i.args[2]), dtype=np.uint32), (64,))
+    a, b = (_s16(a), _s16(b)) if sg == "i" else ((a & _H).astype(np.int64), (b & _H).astype(np.int64))
+    w.wmask(i.args[0], _CMP[c](a, b))
+
+
+for _c in ("lt", "le", "gt", "ge", "eq", "ne"):
+    for _t in ("i16", "u16"):
+        for _s in ("_e32", "_e64"):
+            OPS[f"v_cmp_{_c}_{_t}{_s}"] = _vcmp16
+
+
 @op("v_ashrrev_i64")
 def _(w, i):
     sh = np.broadcast_to(np.asarray(w.rv32(i.args[1]), dtype=np.uint32), (64,)).astype(np.int64) & np.int64(63)
