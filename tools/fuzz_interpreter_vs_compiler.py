@@ -13,6 +13,9 @@ programs: each case generates one HIP kernel out of language-defined building bl
     lanes that took the branch take part); wave-uniform loops that run until no lane of the wavefront has work left,
   * global loads of 4, 8 and 16 bytes; global atomics (add / or / and / xor / max / min) on a small table, results unused -- what
     LLVM's atomic optimizer turns into a wave reduction and one atomic per wavefront,
+  * half of the programs end in a ticket loop (tiles drawn from an atomic counter, broadcast through LDS, barriers inside a
+    wave-uniform loop: the product's persistent-kernel shape), a third in a chain across the workgroups (wait for the predecessor's
+    flag, add, publish -- release / acquire at agent scope, or flag and sum in one 8-byte relaxed atomic as the product's look-back has it),
   * with --intrinsics, the gfx950 builtins the product's kernels lean on (perm, alignbit, alignbyte, ubfe / sbfe, mbcnt, ds_bpermute,
     ds_permute, readlane, readfirstlane, and DPP moves -- quad_perm, row_shl / shr / ror, wave_shl / shr / rol / ror, row_mirror,
     row_half_mirror, row_bcast:15 / 31, with row / bank masks and bound_ctrl, alone and where the compiler's DPP combiner folds them
@@ -26,7 +29,11 @@ a case is the compiler's race, reported as "compiler-sunk-load") and then recomp
 selector (GlobalISel): if that build runs to the host's answer it is reported as "codegen-disagreement", for a human to read;
 what is still wrong then is held against tools/audit_bitop3.py (the v_bitop3 truth-table defect both selectors share): "compiler-bitop3".
 
-    python3 tools/fuzz_interpreter_vs_compiler.py --seed 1 --cases 100 [--opt O1|O2|O3] [--keep DIR]
+Further legs: --model (the same device text on the functional model tests/wavesim, under a random fiber schedule) and, on a GPU box,
+--hardware (the code object on the device: its words must be the interpreter's).  The interpreter's schedule varies with the case
+(index order / reverse / reshuffled every pass; 60 - 2 500 instructions per turn).
+
+    python3 tools/fuzz_interpreter_vs_compiler.py --seed 1 --cases 100 [--opt O1|O2|O3|Os] [--intrinsics] [--model] [--hardware] [--keep DIR]
 """
 import argparse
 import collections
