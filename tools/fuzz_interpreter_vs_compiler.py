@@ -123,6 +123,13 @@ class Gen:
             f"(uint32_t) (int32_t) (int16_t) {x}", f"(uint32_t) (int32_t) (int8_t) ({x} >> {r.choice([0, 8, 16])}u)",
             f"{x} / ({y} | 1u)", f"{x} % ({y} | 1u)",
         ]
+        # byte and halfword shuffles of two words (what the compiler's v_perm_b32 / SDWA / v_alignbyte matchers feed on)
+        def pick(j):
+            src, i = r.choice([x, y]), r.randrange(4)
+            return f"((({src} >> {8 * i}u) & 0xffu) << {8 * j}u)"
+        forms += [" | ".join(pick(j) for j in range(4)), " | ".join(pick(j) for j in r.sample(range(4), 3)),
+                  f"({x} << 16) | ({y} >> 16)", f"({x} & 0xffff0000u) | ({y} & 0xffffu)", f"({x} >> 16) | ({y} & 0xffff0000u)",
+                  f"(({x} & 0x00ff00ffu) << 8) | (({x} >> 8) & 0x00ff00ffu)", f"({x} & 0xff00ff00u) | (({y} >> 8) & 0x00ff00ffu)"]
         if self.intrinsics:  # gfx950 builtins the product's kernels lean on; their host meaning is HOST_PRELUDE's (from the ISA manual)
             sel = sum(r.choice([0, 1, 2, 3, 4, 5, 6, 7, 0x0c]) << (8 * j) for j in range(4))
             forms += [
