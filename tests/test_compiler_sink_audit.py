@@ -84,9 +84,10 @@ def test_reproducer_is_seen_by_the_audit_and_by_the_interpreter(tmp_path, sink):
         assert right  # (a compiler that no longer sinks the load)
 
 
-# ---- the second finding of the differential fuzz: SelectionDAG loses the high half of `uniform64 | ~zext(u32)` ---------------------
+# ---- the second finding of the differential fuzz: SelectionDAG loses the high half of `x64 | ~zext(u32)` ---------------------------
 # (AMD LLVM 22.0.0git of ROCm 7.2, hipcc -O1 .. -O3, gfx950 and gfx90a alike: when the ~zext value has a second use, the high half of
-# the OR -- all ones, whatever x is -- is taken from a register that was never loaded; GlobalISel compiles the same IR correctly.)
+# the OR -- all ones, whatever x is, uniform or per lane -- is taken from a register that was never written; GlobalISel compiles the
+# same IR correctly.)
 # Nothing static can audit the product for a wrong instruction selection: that is what executing the BUILT code objects against the
 # oracle is for (tests/test_gfx950_exec.py, the -m gpu suite rehearsed on the interpreter).  Here the 6-line kernel is the control
 # that the interpreter tells the two builds apart.
