@@ -765,9 +765,21 @@ def _valu(nsrc, fn, name=None):
         if i.op.endswith("_dpp"):
             srcs[0], mask = _dpp_source(w, i, srcs[0])
         if i.op.endswith("_sdwa"):  # sub-dword source selection (zero-extended), full-dword destination only
-            if i.mods.get("dst_sel", "DWORD") != "DWORD" or any(a.startswith(("-", "|")) for a in i.args[1:]):
+            if any(a.startswith(("-", "|")) for a in i.args[1:]):
                 raise Unsupported(i.text)
             srcs = [_sdwa_src(x, i.mods.get(f"src{k}_sel", "DWORD"), i.args[1 + k].startswith("sext(")) for k, x in enumerate(srcs)]
+            if i.mods.get("dst_sel", "DWORD") != "DWORD":
+                # the result's low byte / word goes to the selected place; the rest of the destination: zeros (UNUSED_PAD) or kept (UNUSED_PRESERVE)
+                sh, bits = _SDWA_SEL[i.mods["dst_sel"]]
+                field = np.uint32(((1 << bits) - 1) << sh)
+                r = (np.broadcast_to(fn(*[np.asarray(s_, dtype=np.uint32) for s_ in srcs]), (64,)).astype(np.uint32) << np.uint32(sh)) & field
+                how = i.mods.get("dst_unused", "UNUSED_PAD")
+                if how == "UNUSED_PRESERVE":
+                    r = r | (np.asarray(w.rv32(i.args[0]), dtype=np.uint32) & ~field)
+                elif how != "UNUSED_PAD":
+                    raise Unsupported(i.text)
+                w.wv32(i.args[0], r, mask)
+                return
         w.wv32(i.args[0], fn(*[np.asarray(s, dtype=np.uint32) for s in srcs]), mask)
     return h
 

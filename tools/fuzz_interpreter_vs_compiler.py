@@ -173,6 +173,18 @@ class Gen:
     def statement(self):
         r = self.r
         k = r.random()
+        if k < 0.04:
+            # a butterfly step of a bit transpose (the product's transposes are chains of these): t = ((x >> k) ^ y) & m; y ^= t; x ^= t << k
+            wide = r.random() < 0.4
+            pool = self.v64 if wide else self.v32
+            x, y = r.choice(pool), r.choice(pool)
+            kk, m = r.choice([(1, 0x5555555555555555), (2, 0x3333333333333333), (4, 0x0f0f0f0f0f0f0f0f), (8, 0x00ff00ff00ff00ff), (16, 0x0000ffff0000ffff)] + ([(32, 0xffffffff)] if wide else []))
+            m &= (1 << (64 if wide else 32)) - 1
+            suf = "ull" if wide else "u"
+            t = self.new(wide)
+            y2 = self.new(wide)
+            x2 = self.new(wide)
+            return ("multi", [("set", t, wide, f"(({{{x}}} >> {kk}u) ^ {{{y}}}) & {m:#x}{suf}"), ("set", y2, wide, f"{{{y}}} ^ {{{t}}}"), ("set", x2, wide, f"{{{x}}} ^ ({{{t}}} << {kk}u)")])
         if k < 0.50:
             return self.plain()
         if k < 0.68:
@@ -329,7 +341,10 @@ def device_source(g: Gen) -> str:
     def emit(s, ind):
         pad = "    " * ind
         k = s[0]
-        if k == "set":
+        if k == "multi":
+            for x in s[1]:
+                emit(x, ind)
+        elif k == "set":
             o.append(f"{pad}{'uint64_t' if s[2] else 'uint32_t'} {s[1]} = {_fmt(s[3], False)};")
         elif k == "upd":
             o.append(f"{pad}{s[1]} = {_fmt(s[3], False)};")
@@ -487,7 +502,10 @@ def host_source(g: Gen) -> str:
                 o.append(f"{pad}    if ({_fmt(stop, True)}) break;")
             o.append(f"{pad}}}")
 
+    flat = []
     for s in g.stmts:
+        flat += s[1] if s[0] == "multi" else [s]
+    for s in flat:
         k = s[0]
         if k == "set":
             o.append(f"    std::vector<{'uint64_t' if s[2] else 'uint32_t'}> {s[1]}(N);")
