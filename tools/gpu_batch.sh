@@ -69,9 +69,11 @@ explain)
   #   wg3 = HEAD held to 3 wavefronts per SIMD (f32 kernels): what the 4th workgroup per CU buys.   All checked bit-exact on the CPU
   #   beforehand (tools/variant_parity_cpu.py).  (A 128-work-item f32 tile -- two independent 2-wavefront pipelines -- is NOT rebuilt:
   #   round 1 measured one hypercube per 128-thread workgroup at 0.437 ms against 0.20: twice the tickets, descriptors, look-backs.)
+  #   nosink = HEAD compiled with -mllvm -disable-machine-sink (docs/compiler_findings.md, finding 1: the pass sinks no load in these kernels;
+  #   this build says what the ALU instructions it does move are worth, and is the bisecting aid should a barrier race ever be suspected)
   #   f64sched = the 64-bit stencil without a borrow chain (round 6: every residual as X + ~Y + 1 over v_lshl_add_u64 sums; s_nop executed per
   #   f64 hypercube 334 -> 188 (3D), 345 -> 214 (2D), 259 -> 177 (1D) for +2..4 % VALU; profiles/r06_f64sched.txt) -- judged on the f64 legs only
-  V="main"; for v in r05a trearly cobatch2 winpub wg3 f64sched r04 r03 r02 plainloads plain; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
+  V="main"; for v in r05a trearly cobatch2 winpub wg3 f64sched nosink r04 r03 r02 plainloads plain; do [ -f ndzip_amd/_variants/$v.so ] && V="$V $v"; done
   # (both launch times: round 1 measured cache-policy hints moving time BETWEEN the two kernels -- nt input loads: compress 0.193 vs
   # 0.20 ms alone, decompress +13 % in the full loop, profiles/r01_ablation_notes.txt -- so plainloads is judged on the pair)
   (AB_MODE=both timeout 900 bash tools/ab.sh "$V" 2>&1) > ${O}_ab_variants.txt; cat ${O}_ab_variants.txt

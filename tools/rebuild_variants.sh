@@ -24,5 +24,8 @@ timing -DNDZIP_EXP_KNOBS -DNDZIP_EXP_PHASE_TIMING
 knobs -DNDZIP_EXP_KNOBS -DNDZIP_EXP_ABLATION
 f64sched -DNDZIP_EXP_F64_NOCARRY
 LIST
+# HEAD compiled without the pass that (in this image's compiler) can sink a load past a barrier -- it sinks none in these kernels
+# (tools/audit_machine_sink.py), so this is HEAD with 76-90 ALU instructions per kernel left where the scheduler put them: a bisecting aid
+bash tools/build_variant.sh nosink -mllvm -disable-machine-sink 2>&1 | grep -v "warning\|^In file\|tick_dummy\|^ *[0-9]* |\|\^" | tail -1
 python -c "from ndzip_amd import build; build.build_test_variants()"   # plain (no inline asm, no scalar pins), spin0
-python tools/variant_parity_cpu.py winpub trearly cobatch2 wg3 plainloads f64sched
+python tools/variant_parity_cpu.py winpub trearly cobatch2 wg3 plainloads f64sched nosink
