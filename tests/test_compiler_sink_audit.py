@@ -163,3 +163,47 @@ def test_bitop3_reproducer_is_flagged_and_its_table_is_known(tmp_path):
     assert not tool.scan_ir(tree)[0]
     got = tool.emitted_table(tree, str(tmp_path))
     assert got in (None, (A & X) | (b ^ X)), hex(got)
+
+
+# ---- the fourth finding: v_perm_b32 formation looks through `ashr (amdgcn.perm ...), 8k` past the end of the word -------------------
+# (SelectionDAG, gfx950 and gfx90a; tools/audit_perm_sra.py.)  The bytes that should be copies of the sign come out as the low bytes.
+
+def _perm_tool():
+    spec = importlib.util.spec_from_file_location("audit_perm_sra", os.path.join(ROOT, "tools", "audit_perm_sra.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("unit", ["kernels_f32", "kernels_f64", "capi"])
+def test_the_product_never_shifts_a_perm_result_arithmetically_by_whole_bytes(tmp_path, unit):
+    tool = _perm_tool()
+    hits, nperm, nshift = tool.audit(os.path.join(ROOT, "ndzip_amd", "csrc", unit + ".hip"), tool.PRODUCT_FLAGS, str(tmp_path))
+    assert not hits, hits[:5]
+    assert (nperm > 500 and nshift > 100) or unit == "capi"  # (the scan does see the builtin's calls and the `lshr 4` applied to their results)
+
+
+def test_perm_under_an_arithmetic_shift_is_told_apart_from_globalisel(tmp_path):
+    from tests import gfx950_exec as gx
+
+    tool = _perm_tool()
+    src = tmp_path / "perm.hip"
+    src.write_text(tool.REPRODUCER)
+    assert len(tool.audit(str(src), ["-O3"], str(tmp_path))[0]) == 1
+    x = np.random.default_rng(5).integers(0, 1 << 32, size=1024, dtype=np.uint64).astype(np.uint32)
+    d = x[512:]
+    sign = np.where((d >> np.uint32(16)) & np.uint32(0x80), 0xFF, 0).astype(np.uint32)
+    want = sign | (((d >> np.uint32(24)) & np.uint32(0xFF)) << np.uint32(8)) | (sign << np.uint32(16)) | (((d >> np.uint32(8)) & np.uint32(0xFF)) << np.uint32(24))
+    right = {}
+    for name, flags in (("selectiondag", []), ("globalisel", ["-mllvm", "-global-isel", "-mllvm", "-global-isel-abort=2"])):
+        co = tmp_path / f"{name}.hsaco"
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "--genco", "--no-gpu-bundle-output", *flags, str(src), "-o", str(co)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        k = gx.Kernel(gx.CodeObject(str(co)), "k_perm")
+        assert not k.missing, k.missing
+        got = np.zeros(512, dtype=np.uint32)
+        gx.run_grid(k, 2, 256, 0, struct.pack("<QQ", x.ctypes.data, got.ctypes.data), resident=2, quantum=400)
+        right[name] = bool(np.array_equal(got, want))
+        if not right[name]:  # only the two sign bytes are lost
+            assert np.array_equal(got & np.uint32(0xFF00FF00), want & np.uint32(0xFF00FF00))
+    assert right["globalisel"], right

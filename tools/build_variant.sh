@@ -38,4 +38,8 @@ echo "$audit" | tail -1
 audit=$(python3 "$root/tools/audit_bitop3.py" "$src/kernels_f32.hip" "$src/kernels_f64.hip" "$src/capi.hip" "$@") \
   || { echo "$audit" | tail -8 >&2; echo "build_variant: $name: a bitwise expression has the shape this compiler fuses wrongly -- variant removed" >&2; rm -f "$out/$name.so"; exit 1; }
 echo "$audit" | tail -1
+# ... and read the low bytes of a perm result where its sign is asked for (tools/audit_perm_sra.py)
+audit=$(python3 "$root/tools/audit_perm_sra.py" "$src/kernels_f32.hip" "$src/kernels_f64.hip" "$src/capi.hip" "$@") \
+  || { echo "$audit" | tail -8 >&2; echo "build_variant: $name: an arithmetic byte shift of a perm result -- variant removed" >&2; rm -f "$out/$name.so"; exit 1; }
+echo "$audit" | tail -1
 echo "$out/$name.so"
