@@ -130,6 +130,11 @@ class Gen:
         forms += [" | ".join(pick(j) for j in range(4)), " | ".join(pick(j) for j in r.sample(range(4), 3)),
                   f"({x} << 16) | ({y} >> 16)", f"({x} & 0xffff0000u) | ({y} & 0xffffu)", f"({x} >> 16) | ({y} & 0xffff0000u)",
                   f"(({x} & 0x00ff00ffu) << 8) | (({x} >> 8) & 0x00ff00ffu)", f"({x} & 0xff00ff00u) | (({y} >> 8) & 0x00ff00ffu)"]
+        # nibble, bit-pair and single-bit interleaves (the inner steps of the product's 32 x 32 / 64 x 64 bit transposes)
+        forms += [f"(({x} >> 4) & 0x0f0f0f0fu) | (({y} << 4) & 0xf0f0f0f0u)", f"({x} & 0x0f0f0f0fu) | (({y} & 0x0f0f0f0fu) << 4)",
+                  f"(({x} >> 2) & 0x33333333u) | ({y} & 0xccccccccu)", f"(({x} >> 1) & 0x55555555u) | (({y} << 1) & 0xaaaaaaaau)",
+                  f"__builtin_amdgcn_perm({x}, {y}, 0x07030602u) >> 4" if self.intrinsics else f"({x} >> 4) ^ ({y} << 28)",
+                  f"((__builtin_amdgcn_perm({x}, {y}, 0x05010400u) >> 4) & 0x0f0f0f0fu) | (__builtin_amdgcn_perm({x}, {y}, 0x05010400u) & 0xf0f0f0f0u)" if self.intrinsics else f"({x} << 4) ^ ({y} >> 28)"]
         if self.intrinsics:  # gfx950 builtins the product's kernels lean on; their host meaning is HOST_PRELUDE's (from the ISA manual)
             sel = sum(r.choice([0, 1, 2, 3, 4, 5, 6, 7, 0x0c]) << (8 * j) for j in range(4))
             forms += [
@@ -154,6 +159,8 @@ class Gen:
             f"(uint64_t) {s} * (uint64_t) {self.x32()}", f"{x} + (uint64_t) {s}", f"({x} << 32) | (uint64_t) {s}",
             f"(uint64_t) __builtin_popcountll({x})", f"(uint64_t) __builtin_clzll({x} | 1ull)", f"(uint64_t) __builtin_ctzll({x} | 0x8000000000000000ull)",
             f"(uint64_t) (int64_t) (int32_t) {s}", f"{x} * 0x9e3779b97f4a7c15ull + {y}", f"({x} == {y}) ? 1ull : ({x} ^ {y})",
+            f"(({x} >> 4) & 0x0f0f0f0f0f0f0f0full) | (({y} << 4) & 0xf0f0f0f0f0f0f0f0ull)", f"(({x} >> 32) | ({y} << 32))", f"(({x} & 0xffffffff00000000ull) | ({y} >> 32))",
+            f"(({x} >> 8) & 0x00ff00ff00ff00ffull) | (({y} << 8) & 0xff00ff00ff00ff00ull)", f"(({x} >> 16) & 0x0000ffff0000ffffull) | (({y} << 16) & 0xffff0000ffff0000ull)",
         ]
         return r.choice(forms)
 
