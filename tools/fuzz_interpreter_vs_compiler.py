@@ -845,8 +845,9 @@ def run_case(seed: int, workdir: str, opt: str, nstmts: int, gx, intrinsics: boo
     if sunk:
         return "compiler-sunk-load", f"{len(sunk)} load(s) moved across a barrier by machine-sink; the interpreter ran the race to a different answer"
     # ... or a disagreement between the compiler's two instruction selectors: the same source through GlobalISel.  If that build
-    # runs to the host's answer, SelectionDAG's code computes something else from the same IR (seen: `or i64 x, ~zext(i32)`
-    # with a second use of the ~zext gets the wrong high half -- tests/test_compiler_sink_audit.py holds the 12-line IR)
+    # runs to the host's answer, SelectionDAG's code computes something else from the same IR (seen: `or i64 x, ~zext(i32)` with a
+    # second use of the ~zext gets the wrong high half; a byte gather over `ashr (perm builtin), 8k` reads low bytes for sign bytes --
+    # docs/compiler_findings.md, findings 2 and 4; tests/test_compiler_sink_audit.py holds both reproducers)
     co2 = os.path.join(workdir, f"case{seed}_gisel.hsaco")
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", f"-{opt}", "--genco", "--no-gpu-bundle-output", "-mllvm", "-global-isel", "-mllvm", "-global-isel-abort=2",
                         dpath, "-o", co2], capture_output=True, text=True)
