@@ -423,7 +423,8 @@ def device_source(g: Gen) -> str:
               f"        const uint32_t mine = (in[blockIdx.x * 7u + 3u] ^ {mix:#x}u) + ({var} & 0u);",
               "        unsigned long long seen = 1ull << 32;",
               "        if (blockIdx.x > 0) {",
-              "            do { seen = __hip_atomic_load(&pairs[blockIdx.x - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(seen >> 32)) __builtin_amdgcn_s_sleep(1); } while (!(seen >> 32));",
+              "            uint32_t polls = 0;   // bounded (a second or so on the device): a predecessor that never publishes is a wrong word, not a hung GPU",
+              "            do { seen = __hip_atomic_load(&pairs[blockIdx.x - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(seen >> 32)) __builtin_amdgcn_s_sleep(1); } while (!(seen >> 32) && ++polls < (1u << 22));",
               "        }",
               "        __hip_atomic_store(&pairs[blockIdx.x], (1ull << 32) | (uint32_t) ((uint32_t) seen + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);",
               "    }"]
@@ -433,7 +434,7 @@ def device_source(g: Gen) -> str:
               f"        const uint32_t mine = (in[blockIdx.x * 7u + 3u] ^ {mix:#x}u) + ({var} & 0u);",
               "        uint32_t before = 0;",
               "        if (blockIdx.x > 0) {",
-              f"            while (__hip_atomic_load(&table[{FLAG_SLOT} + blockIdx.x - 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);",
+              f"            for (uint32_t polls = 0; polls < (1u << 22) && __hip_atomic_load(&table[{FLAG_SLOT} + blockIdx.x - 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++polls) __builtin_amdgcn_s_sleep(1);   // bounded: see the packed form",
               f"            before = __hip_atomic_load(&table[{SUM_SLOT} + blockIdx.x - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);",
               "        }",
               f"        __hip_atomic_store(&table[{SUM_SLOT} + blockIdx.x], before + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);",
