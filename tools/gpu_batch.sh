@@ -4,6 +4,8 @@
 #   tools/gpu_batch.sh first   <tag>   ON THE BOX, first call of a round: smoke -> whole -m gpu suite -> PMC passes (traffic.json, made BEFORE
 #                                      the bench line so that the line can carry roofline.traffic) -> bench.py (the driver's command) ->
 #                                      every BASELINE config + bookends + the f64 decoder A/B.       (worst case ~50 min, usually ~20)
+#   tools/gpu_batch.sh quick   <tag>   ON THE BOX, instead of `first` when the gate opens late: smoke -> core parity tests -> bench line -> kernel-trace
+#                                      summary + FETCH/WRITE passes -> the line with roofline.traffic -> then the whole suite (~5-8 min to the evidence)
 #   tools/gpu_batch.sh explain <tag>   ON THE BOX, second call: what explains the numbers -- A/B against the history / lab variants built on the
 #                                      CPU beforehand (tools/build_variant.sh, tools/build_history_variant.sh), workgroups-per-CU sweep, phase
 #                                      timers of the f32 compress iteration, PMC passes of cfg 3 and of both f64 3D decoders.
@@ -18,7 +20,7 @@
 #                                      traffic.json).  Do NOT touch ndzip_amd/csrc or build.FLAGS afterwards: traffic.json is keyed on
 #                                      kernels_fingerprint() and bench.py refuses counters of another build.
 # Every on-box step has its own timeout and writes its own file under gpurun_out/<tag>_* as soon as it ends.
-stage=${1:?stage: first | explain | stress | poll | collect}; tag=${2:?tag}
+stage=${1:?stage: first | quick | explain | stress | poll | collect}; tag=${2:?tag}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 O=gpurun_out/$tag
@@ -57,6 +59,34 @@ first)
    echo "== cfg 5 slab (3D float64 128x1024x1024, decompress only), 128 work-items"; timeout 200 bash tools/kernel_times.sh --config 5 --f64-work-items 128
    echo "== cfg 5 slab, 256 work-items"; timeout 200 bash tools/kernel_times.sh --config 5 --f64-work-items 256) > ${O}_kernel_times_f64.txt 2>&1
   cat ${O}_kernel_times_f64.txt
+  ;;
+quick)
+  # ON THE BOX, when the gate opens with little of the session left: the evidence that counts most, in ~5-8 minutes, each step its own
+  # file -- smoke, the golden / full-size parity tests (every BASELINE config through the C ABI against the oracle), the driver's bench
+  # line, the rocprofv3 --kernel-trace --stats summary of the same command and the FETCH_SIZE / WRITE_SIZE passes (traffic.json).
+  # `first` stays the call to make when there is time: it runs the whole -m gpu suite in front of all this.
+  rocminfo | grep -E "gfx|Compute Unit" | head -4 > ${O}_rocminfo.txt
+  python -c "from ndzip_amd.build import kernels_fingerprint as k; print('kernels_fingerprint', k())" >> ${O}_rocminfo.txt
+  (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -8) > ${O}_smoke.txt; cat ${O}_smoke.txt
+  (timeout 600 python -m pytest tests/test_hip_golden.py tests/test_hip_codec.py -m gpu -q --maxfail=10 -p no:cacheprovider --timeout 180 2>&1 | tail -40) > ${O}_gputest_core.txt
+  tail -8 ${O}_gputest_core.txt
+  timeout 400 python bench.py > ${O}_bench_n1.json 2> ${O}_bench_n1.err
+  cat ${O}_bench_n1.json; tail -5 ${O}_bench_n1.err
+  (export TMPDIR=/tmp; R=$PWD; P=/tmp/quick_$$; mkdir -p $P; cd /tmp
+   B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o stats -- $B > $P/stats.log 2>&1
+   timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $P/pmc4 -o pmc4 -- $B > $P/pmc4.log 2>&1
+   timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_STALL_sum --output-format csv -d $P/pmc5 -o pmc5 -- $B > $P/pmc5.log 2>&1
+   cd $R
+   python tools/prof_summary.py $P --traffic float32-512x512x512 gpurun_out/traffic.json "${O}_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" > ${O}_rocprofv3_summary.txt 2>&1
+   rm -rf $P)
+  cat ${O}_rocprofv3_summary.txt
+  cp gpurun_out/traffic.json profiles/traffic.json 2>/dev/null
+  # the line again, now that the counters of THIS build exist (roofline.traffic)
+  timeout 300 python bench.py --no-cpu-baseline > ${O}_bench_n1_with_traffic.json 2>> ${O}_bench_n1.err; cat ${O}_bench_n1_with_traffic.json
+  # with what is left: the whole suite (a cut-off call keeps every file above)
+  (timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider --timeout 180 2>&1 | tail -120) > ${O}_gputest.txt
+  tail -30 ${O}_gputest.txt
   ;;
 explain)
   # variants present in ndzip_amd/_variants/ decide the A/B legs:
@@ -139,7 +169,7 @@ poll)
   ;;
 collect)
   dst=${3:-$tag}
-  for f in rocminfo smoke gputest variant_parity bench_n1.json bench_n1_native configs kernel_times_f64 workgroups_per_cu workgroups_per_cu_cfg1 rocprofv3_summary rocprofv3_summary_f64_2d \
+  for f in rocminfo smoke gputest gputest_core bench_n1_with_traffic.json variant_parity bench_n1.json bench_n1_native configs kernel_times_f64 workgroups_per_cu workgroups_per_cu_cfg1 rocprofv3_summary rocprofv3_summary_f64_2d \
            rocprofv3_summary_f64_3d_decode_256 rocprofv3_summary_f64_3d_decode_128 ab_variants ab_variants_cfg1 ab_variants_f64_2d \
            ab_variants_f64_3d ablation phase_timing two_process_stress; do
     for ext in "" .txt; do
