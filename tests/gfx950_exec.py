@@ -883,14 +883,31 @@ def _cndmask(w, i):
         x = x & np.uint32(0x7FFFFFFF) if ab else x
         return x ^ np.uint32(0x80000000) if neg else x
 
-    a, b = src(i.args[1]), src(i.args[2])
     mask = None
+    if i.op.endswith("_sdwa"):  # sub-dword sources (as _valu: zero- or sign-extended selection), the result's low field to dst_sel
+        if any(t.startswith(("-", "|")) for t in i.args[1:3]):
+            raise Unsupported(i.text)
+        a, b = (_sdwa_src(w.rv32(t[5:-1] if t.startswith("sext(") else t), i.mods.get(f"src{k}_sel", "DWORD"), t.startswith("sext("))
+                for k, t in enumerate(i.args[1:3]))
+        r = np.where(sel, b, a).astype(np.uint32)
+        if i.mods.get("dst_sel", "DWORD") != "DWORD":
+            sh, bits = _SDWA_SEL[i.mods["dst_sel"]]
+            field = np.uint32(((1 << bits) - 1) << sh)
+            r = (r << np.uint32(sh)) & field
+            how = i.mods.get("dst_unused", "UNUSED_PAD")
+            if how == "UNUSED_PRESERVE":
+                r = r | (np.asarray(w.rv32(i.args[0]), dtype=np.uint32) & ~field)
+            elif how != "UNUSED_PAD":
+                raise Unsupported(i.text)
+        w.wv32(i.args[0], r)
+        return
+    a, b = src(i.args[1]), src(i.args[2])
     if i.op.endswith("_dpp"):
         a, mask = _dpp_source(w, i, a)
     w.wv32(i.args[0], np.where(sel, b, a), mask)
 
 
-for _s in ("_e32", "_e64", "_dpp", ""):
+for _s in ("_e32", "_e64", "_dpp", "_sdwa", ""):
     OPS["v_cndmask_b32" + _s] = _cndmask
 
 
@@ -1064,6 +1081,22 @@ def _s_bfe_i32(a, b, c):
 
 
 _salu2("s_bfe_i32", 32, _s_bfe_i32)
+
+
+@op("s_bfe_i64", "s_bfe_u64")
+def _(w, i):
+    # S0 is 64 bits wide, S1 one dword: offset = S1[5:0], width = S1[22:16]; a field that runs past bit 63 ends there
+    a, b = w.rs64(i.args[1]), w.rs32(i.args[2])
+    off, n = b & 63, min((b >> 16) & 127, 64)
+    if n == 0:
+        r = 0
+    elif i.op == "s_bfe_i64":
+        f = (_sx(a, 64) >> off) & ((1 << n) - 1)      # (arithmetic shift: sign bits fill a field that reaches past bit 63)
+        r = _sx(f, n) & M64
+    else:
+        r = (a >> off) & ((1 << n) - 1)
+    w.ws64(i.args[0], r)
+    w.scc = int(r != 0)
 
 
 @op("s_bitset1_b32", "s_bitset0_b32")
